@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- samples/sec of the batched tree-ensemble traversal on MI355X.
+
+One "step" = one tahoe_forest_predict over one resident batch (BASELINE.json config 3, "K3": synthetic
+forest of 1000 trees of depth 12 over 256 features, 1M rows, float32).  Inputs and the forest are
+resident in HBM before the timed region (as in the reference, BaseTahoeTest.h:563-573).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1, --shard rows (default): every rank holds the whole forest and its own 1M rows (rows are independent
+    -> no data-path collective); value = N * rows / time; "scaling": "weak".
+N > 1, --shard trees: the forest's trees are split across ranks, every rank sees the same 1M rows, partial
+    float32 sums are combined by one RCCL all-reduce per step; value = rows / time; "scaling": "strong".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+MISSING = -999.0
+
+
+def algorithmic_bytes_per_sample(T, depth, cols, bits_bytes):
+    """the reference's own traversal byte model (main.cu:38-46) made exact for perfect
+    depth-`depth` trees: per (row, tree) `depth` internal visits of one node record (4 B threshold +
+    b B packed bits) and one feature (4 B), plus the leaf record; plus the row once and the prediction."""
+    return T * (depth * (4 + bits_bytes + 4) + (4 + bits_bytes)) + cols * 4 + 4
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--trees", type=int, default=1000)
+    ap.add_argument("--depth", type=int, default=12)
+    ap.add_argument("--cols", type=int, default=256)
+    ap.add_argument("--rows", type=int, default=1_000_000)
+    ap.add_argument("--shard", choices=["rows", "trees"], default="rows")
+    ap.add_argument("--strategy", type=int, default=0, help="0 auto, 1 direct, 2 rowtile")
+    ap.add_argument("--cpu-rows", type=int, default=100_000, help="rows of the batch timed on the CPU oracle")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    import torch
+
+    import tahoe_amd as ta
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    T, D, C, R = args.trees, args.depth, args.cols, args.rows
+    nodes = ta.synth_forest(T, D, C, seed=42)
+    n_per_tree = ta.capi.tree_num_nodes(D)
+    if world > 1 and args.shard == "trees":
+        lo, hi = (T * rank) // world, (T * (rank + 1)) // world
+        my_nodes, my_T, first_row = nodes[lo * n_per_tree: hi * n_per_tree], hi - lo, 0
+    else:
+        my_nodes, my_T, first_row = nodes, T, rank * R
+    data = ta.synth_data(R, C, seed=43, first_row=first_row)
+    x = torch.from_numpy(data).cuda()
+    preds = torch.empty(R, dtype=torch.float32, device="cuda")
+    forest = ta.Forest(my_nodes, my_T, D, C, missing=MISSING)
+    forest.set_strategy(args.strategy)
+    info = forest.info()
+    stream = torch.cuda.current_stream()
+
+    def step():
+        if world > 1 and args.shard == "trees":
+            forest.predict_raw(x, preds, stream=stream)
+            dist.all_reduce(preds)  # RCCL over xGMI: 4 B/row
+            ta.capi.transform_preds(preds, 0, T, 0.0, 0.0, stream=stream)
+        else:
+            forest.predict(x, preds, stream=stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    forest.set_profiling(args.steps)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    kernel_ms = forest.kernel_times_ms()
+    forest.set_profiling(0)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    ms_per_step = dt / args.steps * 1e3
+    total_rows = R * world if (world > 1 and args.shard == "rows") else R
+    value = total_rows / (dt / args.steps)
+
+    # ---- roofline of the dominant (traversal) kernel, per launch on this rank ----
+    b_alg = algorithmic_bytes_per_sample(my_T, D, C, info.bits_bytes) * R
+    k_ms = float(np.mean(kernel_ms)) if len(kernel_ms) else float("nan")
+    achieved = b_alg / (k_ms * 1e-3) / 1e9
+    roofline = {
+        "bound": "hbm", "kernel": "rowtile_kernel" if forest.get_strategy(R) == 2 else "direct_kernel",
+        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+        "kernel_ms_avg": round(k_ms, 4), "kernel_ms_min": round(float(np.min(kernel_ms)), 4) if len(kernel_ms) else None,
+        "algorithmic_bytes_per_launch": b_alg,
+        "compulsory_frac": round(((R * C * 4 + my_T * n_per_tree * (4 + info.bits_bytes) + R * 4) / (k_ms * 1e-3) / 1e9)
+                                 / HBM_PEAK_GBPS, 5),
+    }
+
+    # ---- CPU baseline + parity spot check (rank 0, N = 1 only) ----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        from oracle import oracle
+
+        n_cpu = min(args.cpu_rows, R)
+        tc = time.perf_counter()
+        want, _ = oracle.predict(nodes, T, D, data[:n_cpu], MISSING, threads=1)
+        cpu_s = time.perf_counter() - tc
+        got = preds[:n_cpu].cpu().numpy()
+        exact = bool(np.array_equal(got.view(np.uint32), want.view(np.uint32)))
+        ncores = os.cpu_count() or 1
+        n_all = min(R, n_cpu * min(ncores, 16))
+        tc = time.perf_counter()
+        oracle.predict(nodes, T, D, data[:n_all], MISSING, threads=ncores)
+        cpu_all_s = time.perf_counter() - tc
+        cpu = {
+            "value": round(n_cpu / cpu_s, 1), "unit": "samples/s", "cores": 1, "kind": "port",
+            "sample": f"first {n_cpu} rows of the batch, all {T} trees, single thread (the reference's "
+                      f"predict_on_cpu is single-threaded)",
+            "seconds": round(cpu_s, 2),
+            "all_cores": {"value": round(n_all / cpu_all_s, 1), "cores": ncores, "rows": n_all,
+                          "seconds": round(cpu_all_s, 2)},
+            "gpu_matches_cpu_bitwise_on_sample": exact,
+        }
+        if not exact:
+            raise SystemExit("bench: GPU sums differ from the CPU oracle on the sampled rows")
+
+    if rank == 0:
+        out = {
+            "metric": "samples/sec, 1000-tree depth-12 forest @1M rows (batched tree-ensemble traversal)",
+            "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "us_per_batch": round(ms_per_step * 1e3, 1),
+            "higher_is_better": True,
+            "scaling": "strong" if (world > 1 and args.shard == "trees") else "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"K3: synthetic forest {T} trees depth {D}, {C} features, {R} rows"
+                                   + (" per GPU" if world > 1 and args.shard == "rows" else ""),
+                       "trees": T, "depth": D, "cols": C, "rows_per_step": total_rows,
+                       "sharding": "none" if world == 1 else args.shard,
+                       "strategy": {1: "direct", 2: "rowtile"}.get(forest.get_strategy(R))},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,191 @@
+/*
+ * tahoe_amd.h -- C ABI of libtahoe_amd.so: the MI355X (gfx950) implementation of Tahoe's batched
+ * tree-ensemble traversal.  Plain pointers and sizes only; no HIP, torch or C++ types.
+ *
+ * This is the drop-in boundary for the reference's forest operator API (its layer L3):
+ *   reference                                        -> entry point here
+ *   init_dense / init_dense_adaptive                 -> tahoe_forest_create
+ *     (BaseTahoeTest.h:519-525, :605-611; dense_forest::init Struct.h:815-833;
+ *      dense_adaptive_forest::init Struct.h:1756-1986)
+ *   predict_dense / predict_dense_adaptive           -> tahoe_forest_predict
+ *     (BaseTahoeTest.h:544-547, :599-602; forest::predict Struct.h:245-269)
+ *   global `selected_algorithm` (Struct.h:11)        -> tahoe_forest_set_strategy (per handle)
+ *   delete forest (BaseTahoeTest.h:594,709; leaks)   -> tahoe_forest_destroy (frees device memory)
+ *   generate_forest_from_file / generate_data_from_file (BaseTahoeTest.h:267-402)
+ *                                                    -> tahoe_load_model / tahoe_load_data
+ *   allocate/updateDevice/updateHost (cuda_base.h:28-50), compare_GPU (cuda_base.h:98-111)
+ *                                                    -> tahoe_device_* / tahoe_compare_device
+ * Every device pointer is a HIP device pointer on the handle's device; `stream` is a hipStream_t
+ * passed as void* (NULL = the default stream).  All predict calls are asynchronous on `stream`
+ * and allocate nothing.
+ *
+ * There is no CPU fallback: every compute entry point fails with TAHOE_ERR_NO_DEVICE when no
+ * gfx950 device is usable.
+ */
+#ifndef TAHOE_AMD_H
+#define TAHOE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TAHOE_AMD_ABI_VERSION 1
+
+/* ---- status codes (the reference prints and continues, cuda_base.h:19-25; we return codes) ---- */
+typedef enum {
+    TAHOE_OK = 0,
+    TAHOE_ERR_INVALID_ARG = 1,   /* NULL pointer, negative size, bad enum (check_params, BaseTahoeTest.h:490-516) */
+    TAHOE_ERR_IO = 2,            /* file cannot be opened (BaseTahoeTest.h:273-277, :360-364) */
+    TAHOE_ERR_NO_MEMORY = 3,
+    TAHOE_ERR_NO_DEVICE = 4,     /* no usable gfx950 device: there is no CPU path */
+    TAHOE_ERR_HIP = 5,           /* a HIP runtime call failed; text in tahoe_last_error() */
+    TAHOE_ERR_INVALID_FOREST = 6,/* a reachable bottom-level node is not a leaf / fid >= num_cols */
+    TAHOE_ERR_UNSUPPORTED = 7    /* requested strategy cannot run this shape */
+} tahoe_status;
+
+/* Thread-local text of the last error returned on this thread ("" if none). */
+const char *tahoe_last_error(void);
+int tahoe_abi_version(void);
+
+/* ---- node encoding: dense_node_t, Struct.h:44-48, masks Struct.h:57-59 ---- */
+typedef struct {
+    float weight; /* branch probability; unused at inference */
+    float val;    /* threshold (internal node) or leaf value */
+    int32_t bits; /* fid[0:29] | def_left<<30 | is_leaf<<31 */
+} tahoe_dense_node;
+
+/* encode_node Struct.h:103-108 / dense_node_decode Struct.h:110-117 */
+void tahoe_encode_node(tahoe_dense_node *n, int fid, float value, int def_left, float weight, int is_leaf);
+void tahoe_decode_node(const tahoe_dense_node *n, float *value, float *weight, int *fid, int *def_left,
+                       int *is_leaf);
+/* tree_num_nodes Struct.h:15-17 */
+int tahoe_tree_num_nodes(int depth);
+
+/* ---- enums: algo_t Struct.h:23-27, strategy_t :29-34, output_t :37-42 ---- */
+enum { TAHOE_ALGO_NAIVE = 0, TAHOE_ALGO_TREE_REORG = 1, TAHOE_ALGO_BATCH_TREE_REORG = 2 };
+enum { TAHOE_FIL_SHARED_DATA = 0, TAHOE_FIL_SHARED_FOREST = 1, TAHOE_FIL_SPLIT_FOREST = 2,
+       TAHOE_FIL_SPLIT_FOREST_SHARED_DATA = 3 };
+enum { TAHOE_OUT_RAW = 0x0, TAHOE_OUT_AVG = 0x1, TAHOE_OUT_SIGMOID = 0x10, TAHOE_OUT_THRESHOLD = 0x100 };
+
+/* forest_params_t, Struct.h:166-189 (same fields, same order). */
+typedef struct {
+    int num_nodes;     /* ignored for dense forests */
+    int depth;         /* ps.depth: levels - 1; a tree has 2^(depth+1)-1 nodes */
+    int num_trees;
+    int num_cols;
+    int algo;          /* algo_t; accepted and ignored (the layout is ours) */
+    int output;        /* output_t bit set */
+    float threshold;
+    float global_bias;
+    int strategy;      /* strategy_t of the FIL baseline; accepted and ignored */
+    float missing;     /* "missing" sentinel: |x - missing| <= 1e-6 takes the default branch */
+} tahoe_forest_params;
+
+/* Traversal strategies of this library (the analogue of selected_algorithm 0..4, Struct.h:2168-2179). */
+enum {
+    TAHOE_STRATEGY_AUTO = 0,     /* selector picks from shape and LDS capacity */
+    TAHOE_STRATEGY_DIRECT = 1,   /* lane = row, nodes and features straight from global memory
+                                    (analogue of infer_adaptive_reorg_*, Struct.h:1196-1240) */
+    TAHOE_STRATEGY_ROWTILE = 2   /* 64-row feature-major tile in LDS, waves split the trees, top
+                                    levels of each tree staged in LDS, ordered leaf-sum exchange */
+};
+
+typedef struct tahoe_forest tahoe_forest; /* opaque */
+
+/* Builds the device layout from host nodes in the reference encoding: num_trees trees, each
+ * 2^(depth+1)-1 nodes in heap order (children of i are 2i+1, 2i+2), tree-major (what
+ * generate_forest_from_file produces, BaseTahoeTest.h:319-328).  The forest lives on the current
+ * HIP device.  Validates that every reachable path ends in a leaf inside the tree and that every
+ * reachable fid < num_cols (the reference reads out of bounds instead). */
+tahoe_status tahoe_forest_create(tahoe_forest **out, const tahoe_dense_node *nodes,
+                                 const tahoe_forest_params *params);
+void tahoe_forest_destroy(tahoe_forest *f);
+
+/* preds_dev[rows] <- per-row float32 sum of leaf values in tree order 0..T-1 (the order of
+ * predict_on_cpu, BaseTahoeTest.h:462-466), then AVG / bias / sigmoid / threshold as
+ * forest::predict + transform_k do (Struct.h:196-209, :263-268).  data_dev is row-major
+ * rows x num_cols float32 (data_d of generate_data_from_file, BaseTahoeTest.h:378-392). */
+tahoe_status tahoe_forest_predict(tahoe_forest *f, float *preds_dev, const float *data_dev, size_t rows,
+                                  void *stream);
+
+/* Raw float32 per-row sums only (no output transform) -- the quantity tree shards exchange. */
+tahoe_status tahoe_forest_predict_raw(tahoe_forest *f, float *sums_dev, const float *data_dev, size_t rows,
+                                      void *stream);
+
+/* leaf_dev[row * num_trees + tree] <- index of the leaf the row ends in, in the tree's original heap
+ * numbering (final `curr` of infer_one_tree, BaseTahoeTest.h:441-455).  sums_dev may be NULL. */
+tahoe_status tahoe_forest_predict_leaf_idx(tahoe_forest *f, uint32_t *leaf_dev, float *sums_dev,
+                                           const float *data_dev, size_t rows, void *stream);
+
+/* Finishes sums -> preds in place (AVG, bias, sigmoid, threshold); what the ranks of a tree-sharded
+ * forest call after the all-reduce.  num_trees_total = trees of the whole forest. */
+tahoe_status tahoe_transform_preds(float *preds_dev, size_t rows, int output, int num_trees_total,
+                                   float threshold, float global_bias, void *stream);
+
+tahoe_status tahoe_forest_set_strategy(tahoe_forest *f, int strategy);
+/* Strategy the next predict will run (after AUTO resolution for `rows`). */
+int tahoe_forest_get_strategy(const tahoe_forest *f, size_t rows);
+
+typedef struct {
+    int num_trees, depth, num_cols;
+    int bits_bytes;          /* b of the reference's adaptive format rule (Struct.h:1827-1852): 1, 2 or 4 */
+    int lds_levels;          /* top levels staged in LDS by ROWTILE */
+    size_t device_bytes;     /* device memory owned by the handle */
+    size_t path_len_sum;     /* sum over trees of ... (reserved) */
+    int lds_bytes_per_block; /* dynamic LDS of the ROWTILE kernel */
+    int device_id;
+    int num_cus;
+} tahoe_forest_info;
+tahoe_status tahoe_forest_get_info(const tahoe_forest *f, tahoe_forest_info *info);
+
+/* Kernel timing with hipEvents on the stream the kernel runs on.  set_profiling(f, n) arms up to n
+ * launches (0 disarms): each following predict brackets its traversal kernel with an event pair.
+ * kernel_times waits for the recorded launches and returns their durations in milliseconds. */
+tahoe_status tahoe_forest_set_profiling(tahoe_forest *f, int max_launches);
+tahoe_status tahoe_forest_kernel_times(tahoe_forest *f, float *ms_out, int capacity, int *count);
+
+/* ---- file formats (BaseTahoeTest.h:267-402): one value per line ---- */
+/* model: num_trees, levels(=depth+1), then per tree, per node in heap order: fid, value,
+ * default_left, weight, is_leaf.  *num_trees / *depth are in/out (kept when a header line is
+ * missing, as the reference keeps its constructor defaults).  nodes_out: tahoe_free_host. */
+tahoe_status tahoe_load_model(const char *path, int *num_trees, int *depth, tahoe_dense_node **nodes_out);
+/* data: num_rows, num_cols, missing, then rows*cols values row-major. */
+tahoe_status tahoe_load_data(const char *path, int *num_rows, int *num_cols, float *missing, float **data_out);
+tahoe_status tahoe_write_model(const char *path, int num_trees, int depth, const tahoe_dense_node *nodes);
+tahoe_status tahoe_write_data(const char *path, int num_rows, int num_cols, float missing, const float *data);
+void tahoe_free_host(void *p);
+
+/* ---- deterministic synthetic inputs: SplitMix64, counter-based ---- */
+/* Complete trees: levels < depth internal (fid = x mod num_cols, threshold 2u-1, def_left = x&1),
+ * bottom level leaves (val 2u-1); internal nodes above the bottom turn into leaves with
+ * probability leaf_prob. */
+void tahoe_synth_forest(tahoe_dense_node *nodes, int num_trees, int depth, int num_cols, uint64_t seed,
+                        float leaf_prob);
+/* rows x cols float32 in [-1,1); each value replaced by `missing` with probability missing_prob and
+ * by NaN with probability nan_prob.  first_row lets ranks generate disjoint row ranges. */
+void tahoe_synth_data(float *out, size_t first_row, size_t rows, int num_cols, uint64_t seed,
+                      float missing_prob, float missing, float nan_prob);
+
+/* ---- thin device helpers so that host code above this ABI needs no HIP headers ---- */
+tahoe_status tahoe_device_count(int *count);
+tahoe_status tahoe_device_set(int device);
+tahoe_status tahoe_device_alloc(void **ptr, size_t bytes, int set_zero);   /* allocate(), cuda_base.h:28-32 */
+tahoe_status tahoe_device_free(void *ptr);
+tahoe_status tahoe_copy_to_device(void *dst_dev, const void *src_host, size_t bytes, void *stream);
+tahoe_status tahoe_copy_to_host(void *dst_host, const void *src_dev, size_t bytes, void *stream);
+tahoe_status tahoe_stream_create(void **stream);
+tahoe_status tahoe_stream_destroy(void *stream);
+tahoe_status tahoe_stream_synchronize(void *stream);
+tahoe_status tahoe_device_synchronize(void);
+tahoe_status tahoe_device_lds_bytes(int *bytes);  /* sharedMemPerBlock analogue, Struct.h:215-220 */
+/* compare_GPU, cuda_base.h:98-111: counts i with |a[i]-b[i]| > tol (on the device). */
+tahoe_status tahoe_compare_device(const float *a_dev, const float *b_dev, size_t n, float tol,
+                                  size_t *num_bad, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TAHOE_AMD_H */

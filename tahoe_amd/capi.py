@@ -1,0 +1,306 @@
+"""ctypes binding of include/tahoe_amd.h.
+
+Plumbing only: torch (or anything else) owns device memory and streams; this module passes raw
+device pointers through the C ABI.  If libtahoe_amd.so has not been built the import fails --
+there is deliberately no pure-Python or CPU substitute.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtahoe_amd.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "or `make -C tahoe_amd/csrc`.  tahoe_amd has no fallback path."
+    )
+
+lib = C.CDLL(LIB_PATH)
+
+# ---- constants mirrored from the header ----
+OUT_RAW, OUT_AVG, OUT_SIGMOID, OUT_THRESHOLD = 0x0, 0x1, 0x10, 0x100
+STRATEGY_AUTO, STRATEGY_DIRECT, STRATEGY_ROWTILE = 0, 1, 2
+STATUS_NAMES = {
+    0: "TAHOE_OK",
+    1: "TAHOE_ERR_INVALID_ARG",
+    2: "TAHOE_ERR_IO",
+    3: "TAHOE_ERR_NO_MEMORY",
+    4: "TAHOE_ERR_NO_DEVICE",
+    5: "TAHOE_ERR_HIP",
+    6: "TAHOE_ERR_INVALID_FOREST",
+    7: "TAHOE_ERR_UNSUPPORTED",
+}
+
+# dense_node_t (Struct.h:44-48): weight, val, bits
+NODE_DTYPE = np.dtype([("weight", "<f4"), ("val", "<f4"), ("bits", "<i4")])
+
+
+class ForestParams(C.Structure):
+    """tahoe_forest_params == forest_params_t (Struct.h:166-189)."""
+
+    _fields_ = [
+        ("num_nodes", C.c_int),
+        ("depth", C.c_int),
+        ("num_trees", C.c_int),
+        ("num_cols", C.c_int),
+        ("algo", C.c_int),
+        ("output", C.c_int),
+        ("threshold", C.c_float),
+        ("global_bias", C.c_float),
+        ("strategy", C.c_int),
+        ("missing", C.c_float),
+    ]
+
+
+class ForestInfo(C.Structure):
+    _fields_ = [
+        ("num_trees", C.c_int),
+        ("depth", C.c_int),
+        ("num_cols", C.c_int),
+        ("bits_bytes", C.c_int),
+        ("lds_levels", C.c_int),
+        ("device_bytes", C.c_size_t),
+        ("path_len_sum", C.c_size_t),
+        ("lds_bytes_per_block", C.c_int),
+        ("device_id", C.c_int),
+        ("num_cus", C.c_int),
+    ]
+
+
+class TahoeError(RuntimeError):
+    def __init__(self, status: int, where: str):
+        self.status = status
+        msg = lib.tahoe_last_error().decode(errors="replace")
+        super().__init__(f"{where}: {STATUS_NAMES.get(status, status)}: {msg}")
+
+
+def _check(status: int, where: str) -> None:
+    if status != 0:
+        raise TahoeError(status, where)
+
+
+_vp, _sz, _i, _f = C.c_void_p, C.c_size_t, C.c_int, C.c_float
+_PROTOS = {
+    "tahoe_last_error": (C.c_char_p, []),
+    "tahoe_abi_version": (_i, []),
+    "tahoe_encode_node": (None, [_vp, _i, _f, _i, _f, _i]),
+    "tahoe_decode_node": (None, [_vp] + [_vp] * 5),
+    "tahoe_tree_num_nodes": (_i, [_i]),
+    "tahoe_forest_create": (_i, [C.POINTER(_vp), _vp, C.POINTER(ForestParams)]),
+    "tahoe_forest_destroy": (None, [_vp]),
+    "tahoe_forest_predict": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "tahoe_forest_predict_raw": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "tahoe_forest_predict_leaf_idx": (_i, [_vp, _vp, _vp, _vp, _sz, _vp]),
+    "tahoe_transform_preds": (_i, [_vp, _sz, _i, _i, _f, _f, _vp]),
+    "tahoe_forest_set_strategy": (_i, [_vp, _i]),
+    "tahoe_forest_get_strategy": (_i, [_vp, _sz]),
+    "tahoe_forest_get_info": (_i, [_vp, C.POINTER(ForestInfo)]),
+    "tahoe_forest_set_profiling": (_i, [_vp, _i]),
+    "tahoe_forest_kernel_times": (_i, [_vp, _vp, _i, C.POINTER(_i)]),
+    "tahoe_load_model": (_i, [C.c_char_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_vp)]),
+    "tahoe_load_data": (_i, [C.c_char_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_f), C.POINTER(_vp)]),
+    "tahoe_write_model": (_i, [C.c_char_p, _i, _i, _vp]),
+    "tahoe_write_data": (_i, [C.c_char_p, _i, _i, _f, _vp]),
+    "tahoe_free_host": (None, [_vp]),
+    "tahoe_synth_forest": (None, [_vp, _i, _i, _i, C.c_uint64, _f]),
+    "tahoe_synth_data": (None, [_vp, _sz, _sz, _i, C.c_uint64, _f, _f, _f]),
+    "tahoe_device_count": (_i, [C.POINTER(_i)]),
+    "tahoe_device_set": (_i, [_i]),
+    "tahoe_device_alloc": (_i, [C.POINTER(_vp), _sz, _i]),
+    "tahoe_device_free": (_i, [_vp]),
+    "tahoe_copy_to_device": (_i, [_vp, _vp, _sz, _vp]),
+    "tahoe_copy_to_host": (_i, [_vp, _vp, _sz, _vp]),
+    "tahoe_stream_create": (_i, [C.POINTER(_vp)]),
+    "tahoe_stream_destroy": (_i, [_vp]),
+    "tahoe_stream_synchronize": (_i, [_vp]),
+    "tahoe_device_synchronize": (_i, []),
+    "tahoe_device_lds_bytes": (_i, [C.POINTER(_i)]),
+    "tahoe_compare_device": (_i, [_vp, _vp, _sz, _f, C.POINTER(_sz), _vp]),
+}
+for _name, (_res, _args) in _PROTOS.items():
+    _fn = getattr(lib, _name)  # AttributeError here = the library does not export a declared symbol
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+EXPORTED_SYMBOLS = tuple(_PROTOS)
+
+
+# ---- host-side helpers (formats, synthetic inputs) ----
+def tree_num_nodes(depth: int) -> int:
+    return lib.tahoe_tree_num_nodes(depth)
+
+
+def load_model(path: str, num_trees: int = 10, depth: int = 20):
+    """-> (nodes[NODE_DTYPE], num_trees, depth).  Defaults are the BaseTahoeTest ctor defaults."""
+    nt, d, ptr = _i(num_trees), _i(depth), _vp()
+    _check(lib.tahoe_load_model(os.fsencode(path), C.byref(nt), C.byref(d), C.byref(ptr)), "tahoe_load_model")
+    n = nt.value * tree_num_nodes(d.value)
+    try:
+        buf = (C.c_char * (n * NODE_DTYPE.itemsize)).from_address(ptr.value) if n else b""
+        nodes = np.frombuffer(buf, dtype=NODE_DTYPE, count=n).copy()
+    finally:
+        lib.tahoe_free_host(ptr)
+    return nodes, nt.value, d.value
+
+
+def load_data(path: str, num_rows: int = 1000, num_cols: int = 500, missing: float = 0.0):
+    """-> (data[rows, cols] float32, missing)."""
+    nr, nc, ms, ptr = _i(num_rows), _i(num_cols), _f(missing), _vp()
+    _check(lib.tahoe_load_data(os.fsencode(path), C.byref(nr), C.byref(nc), C.byref(ms), C.byref(ptr)),
+           "tahoe_load_data")
+    n = nr.value * nc.value
+    try:
+        buf = (C.c_char * (n * 4)).from_address(ptr.value) if n else b""
+        data = np.frombuffer(buf, dtype=np.float32, count=n).copy().reshape(nr.value, nc.value)
+    finally:
+        lib.tahoe_free_host(ptr)
+    return data, ms.value
+
+
+def write_model(path: str, nodes: np.ndarray, num_trees: int, depth: int) -> None:
+    nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
+    assert nodes.size == num_trees * tree_num_nodes(depth)
+    _check(lib.tahoe_write_model(os.fsencode(path), num_trees, depth, nodes.ctypes.data), "tahoe_write_model")
+
+
+def write_data(path: str, data: np.ndarray, missing: float) -> None:
+    data = np.ascontiguousarray(data, dtype=np.float32)
+    _check(lib.tahoe_write_data(os.fsencode(path), data.shape[0], data.shape[1], missing, data.ctypes.data),
+           "tahoe_write_data")
+
+
+def synth_forest(num_trees: int, depth: int, num_cols: int, seed: int = 42, leaf_prob: float = 0.0) -> np.ndarray:
+    nodes = np.empty(num_trees * tree_num_nodes(depth), dtype=NODE_DTYPE)
+    lib.tahoe_synth_forest(nodes.ctypes.data, num_trees, depth, num_cols, seed, leaf_prob)
+    return nodes
+
+
+def synth_data(rows: int, num_cols: int, seed: int = 43, missing_prob: float = 0.0, missing: float = -999.0,
+               nan_prob: float = 0.0, first_row: int = 0) -> np.ndarray:
+    data = np.empty((rows, num_cols), dtype=np.float32)
+    lib.tahoe_synth_data(data.ctypes.data, first_row, rows, num_cols, seed, missing_prob, missing, nan_prob)
+    return data
+
+
+def encode_nodes(fid, value, def_left, weight, is_leaf) -> np.ndarray:
+    """Vector form of encode_node (Struct.h:103-108) for building test forests by hand."""
+    fid = np.asarray(fid, dtype=np.int64)
+    nodes = np.empty(fid.shape, dtype=NODE_DTYPE)
+    nodes["weight"] = np.asarray(weight, dtype=np.float32)
+    nodes["val"] = np.asarray(value, dtype=np.float32)
+    bits = (fid & ((1 << 30) - 1)) | (np.asarray(def_left, dtype=np.int64) != 0) * (1 << 30) | (
+        np.asarray(is_leaf, dtype=np.int64) != 0) * (1 << 31)
+    nodes["bits"] = bits.astype(np.uint32).view(np.int32)
+    return nodes
+
+
+# ---- the forest operator ----
+def _ptr(t) -> int:
+    """Device pointer of a torch tensor (or a raw int address)."""
+    return t if isinstance(t, int) else t.data_ptr()
+
+
+def _stream(stream) -> int:
+    if stream is None:
+        import torch
+
+        return torch.cuda.current_stream().cuda_stream
+    return stream if isinstance(stream, int) else stream.cuda_stream
+
+
+class Forest:
+    """Handle on a device forest: tahoe_forest_create / predict / destroy.
+
+    Mirrors the reference's init_dense* + predict_dense* pair (BaseTahoeTest.h:519-547, :599-611).
+    Tensors are torch CUDA tensors (float32 data [rows, cols] contiguous, float32 preds [rows])."""
+
+    def __init__(self, nodes: np.ndarray, num_trees: int, depth: int, num_cols: int, missing: float = 0.0,
+                 output: int = OUT_RAW, threshold: float = 0.0, global_bias: float = 0.0, algo: int = 0,
+                 strategy: int = 0):
+        nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
+        if nodes.size != num_trees * tree_num_nodes(depth):
+            raise ValueError("nodes.size != num_trees * tree_num_nodes(depth)")
+        self.params = ForestParams(0, depth, num_trees, num_cols, algo, output, threshold, global_bias, strategy,
+                                   missing)
+        self._h = _vp()
+        _check(lib.tahoe_forest_create(C.byref(self._h), nodes.ctypes.data if nodes.size else None,
+                                       C.byref(self.params)), "tahoe_forest_create")
+        self.num_trees, self.depth, self.num_cols = num_trees, depth, num_cols
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib.tahoe_forest_destroy(self._h)
+            self._h = _vp()
+
+    __del__ = close
+
+    def _check_data(self, data):
+        assert data.is_cuda and data.is_contiguous() and data.dtype.is_floating_point and data.element_size() == 4
+        assert data.dim() == 2 and data.shape[1] == self.num_cols, (tuple(data.shape), self.num_cols)
+
+    def predict(self, data, preds=None, stream=None):
+        import torch
+
+        self._check_data(data)
+        rows = data.shape[0]
+        if preds is None:
+            preds = torch.empty(rows, dtype=torch.float32, device=data.device)
+        _check(lib.tahoe_forest_predict(self._h, _ptr(preds), _ptr(data), rows, _stream(stream)),
+               "tahoe_forest_predict")
+        return preds
+
+    def predict_raw(self, data, sums=None, stream=None):
+        import torch
+
+        self._check_data(data)
+        rows = data.shape[0]
+        if sums is None:
+            sums = torch.empty(rows, dtype=torch.float32, device=data.device)
+        _check(lib.tahoe_forest_predict_raw(self._h, _ptr(sums), _ptr(data), rows, _stream(stream)),
+               "tahoe_forest_predict_raw")
+        return sums
+
+    def predict_leaf_idx(self, data, want_sums: bool = True, stream=None):
+        import torch
+
+        self._check_data(data)
+        rows = data.shape[0]
+        leaf = torch.empty((rows, self.num_trees), dtype=torch.int32, device=data.device)
+        sums = torch.empty(rows, dtype=torch.float32, device=data.device) if want_sums else None
+        _check(lib.tahoe_forest_predict_leaf_idx(self._h, _ptr(leaf), _ptr(sums) if want_sums else None,
+                                                 _ptr(data), rows, _stream(stream)),
+               "tahoe_forest_predict_leaf_idx")
+        return leaf, sums
+
+    def set_strategy(self, strategy: int) -> None:
+        _check(lib.tahoe_forest_set_strategy(self._h, strategy), "tahoe_forest_set_strategy")
+
+    def get_strategy(self, rows: int) -> int:
+        return lib.tahoe_forest_get_strategy(self._h, rows)
+
+    def info(self) -> ForestInfo:
+        info = ForestInfo()
+        _check(lib.tahoe_forest_get_info(self._h, C.byref(info)), "tahoe_forest_get_info")
+        return info
+
+    def set_profiling(self, max_launches: int) -> None:
+        _check(lib.tahoe_forest_set_profiling(self._h, int(max_launches)), "tahoe_forest_set_profiling")
+
+    def kernel_times_ms(self, capacity: int = 4096) -> np.ndarray:
+        """Durations (ms) of the traversal kernels launched since set_profiling; waits for them."""
+        out = np.empty(capacity, dtype=np.float32)
+        n = _i()
+        _check(lib.tahoe_forest_kernel_times(self._h, out.ctypes.data, capacity, C.byref(n)),
+               "tahoe_forest_kernel_times")
+        return out[: n.value].copy()
+
+
+def transform_preds(preds, output: int, num_trees_total: int, threshold: float, global_bias: float, stream=None):
+    _check(lib.tahoe_transform_preds(_ptr(preds), preds.numel(), output, num_trees_total, threshold, global_bias,
+                                     _stream(stream)), "tahoe_transform_preds")
+    return preds

@@ -1,0 +1,249 @@
+"""Parity of the HIP traversal (through the C ABI) against the CPU oracle.  Needs an MI355X.
+
+Bars: leaf indices bit-exact; raw float32 sums bit-exact (the kernels add in the CPU's tree order);
+outputs with a sigmoid within 1e-6 relative (device expf vs glibc expf), everything else bit-exact.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+MISSING = -999.0
+
+
+@pytest.fixture(scope="module")
+def env(built):
+    import torch
+
+    import tahoe_amd as ta
+    from oracle import oracle
+
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    torch.cuda.set_device(0)
+    return ta, oracle, torch
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def run_case(env, nodes, T, D, C, data, strategies=None, missing=MISSING, **out):
+    ta, oracle, torch = env
+    want, want_leaf = oracle.predict(nodes, T, D, data, missing, want_leaf=True)
+    x = torch.from_numpy(np.ascontiguousarray(data)).cuda()
+    forest = ta.Forest(nodes, T, D, C, missing=missing)
+    lds_ok = forest.info().lds_bytes_per_block > 0
+    if strategies is None:
+        strategies = [ta.STRATEGY_DIRECT] + ([ta.STRATEGY_ROWTILE] if lds_ok else []) + [ta.STRATEGY_AUTO]
+    for s in strategies:
+        forest.set_strategy(s)
+        leaf, sums = forest.predict_leaf_idx(x)
+        raw = forest.predict_raw(x)
+        torch.cuda.synchronize()
+        assert np.array_equal(bits(leaf.cpu().numpy()), want_leaf), f"leaf index mismatch, strategy {s}"
+        assert np.array_equal(bits(sums.cpu().numpy()), bits(want)), f"sum (leaf pass) mismatch, strategy {s}"
+        assert np.array_equal(bits(raw.cpu().numpy()), bits(want)), f"sum mismatch, strategy {s}"
+    forest.close()
+    return want, want_leaf
+
+
+SHAPES = [
+    # T, D, C, R, leaf_prob
+    (1, 0, 1, 1, 0.0),
+    (3, 1, 2, 5, 0.0),
+    (4, 2, 3, 64, 0.3),
+    (7, 3, 18, 100, 0.2),
+    (50, 6, 32, 1000, 0.1),
+    (5, 8, 17, 129, 0.0),       # cols not a multiple of 4 -> scalar tile staging
+    (130, 8, 256, 777, 0.05),
+    (21, 9, 64, 300, 0.0),      # one level below the LDS-staged top
+    (20, 12, 256, 2000, 0.0),   # K3 shape, small
+    (9, 12, 256, 511, 0.15),
+    (33, 10, 500, 129, 0.0),    # 125 KiB tile: one workgroup per CU
+    (6, 7, 3072, 200, 0.0),     # K2-like width: the row tile does not fit LDS -> DIRECT only
+    (3, 14, 40, 97, 0.02),
+]
+
+
+@pytest.mark.parametrize("T,D,C,R,leaf_prob", SHAPES)
+def test_random_forests(env, T, D, C, R, leaf_prob):
+    ta = env[0]
+    nodes = ta.synth_forest(T, D, C, seed=100 + T, leaf_prob=leaf_prob)
+    data = ta.synth_data(R, C, seed=200 + R, missing_prob=0.05, missing=MISSING, nan_prob=0.02)
+    run_case(env, nodes, T, D, C, data)
+
+
+def test_threshold_ties_and_missing_band(env):
+    """x == threshold goes right; |x - missing| <= 1e-6 (float32) takes the default branch, both signs of
+    def_left; values just outside the band compare normally; NaN and +-inf features."""
+    ta = env[0]
+    T, D, C, R = 16, 5, 8, 512
+    nodes = ta.synth_forest(T, D, C, seed=5)
+    rng = np.random.default_rng(0)
+    thr = nodes["val"][rng.integers(0, nodes.size, size=(R, C))]  # rows made of actual thresholds
+    data = thr.astype(np.float32)
+    m = np.float32(0.25)  # a missing sentinel in the data range so the band is resolvable in float32
+    band = np.array([m, m + np.float32(5e-7), m - np.float32(5e-7), m + np.float32(1e-6), m - np.float32(1e-6),
+                     m + np.float32(2e-6), m - np.float32(2e-6), np.nextafter(m + np.float32(1e-6), np.float32(1))],
+                    dtype=np.float32)
+    data[:64, :] = band[rng.integers(0, band.size, size=(64, C))]
+    data[64:80, ::2] = np.nan
+    data[80:96, 1::3] = np.inf
+    data[96:112, ::3] = -np.inf
+    run_case(env, nodes, T, D, C, data, missing=float(m))
+
+
+def test_nan_missing_sentinel(env):
+    """missing = NaN: the band test is never true (NaN compares false), NaN features go left."""
+    ta = env[0]
+    T, D, C, R = 8, 4, 6, 200
+    nodes = ta.synth_forest(T, D, C, seed=9)
+    data = ta.synth_data(R, C, seed=10, nan_prob=0.2)
+    run_case(env, nodes, T, D, C, data, missing=float("nan"))
+
+
+def test_early_leaves_with_garbage_below(env):
+    """A leaf above the bottom level ends the walk; whatever the file holds below it is never read."""
+    ta = env[0]
+    T, D, C, R = 12, 7, 10, 400
+    nodes = ta.synth_forest(T, D, C, seed=11, leaf_prob=0.5)  # root itself is a leaf in about half the trees
+    data = ta.synth_data(R, C, seed=12, missing_prob=0.1, missing=MISSING)
+    want, leaf = run_case(env, nodes, T, D, C, data)
+    n = ta.capi.tree_num_nodes(D)
+    assert (leaf < (n >> 1)).any(), "case must contain leaves above the bottom level"
+
+
+def test_hand_built_tree(env):
+    """Known answers derived by hand: depth-2 tree over 2 features.
+         node0: f0 >= 0.5 ? right : left        (def_left = 1)
+         node1: f1 >= -1.0                      (def_left = 0)   node2: leaf 10.0 (early leaf)
+         node3: leaf 1.0   node4: leaf 2.0      nodes 5,6 garbage (below the leaf)"""
+    ta, oracle, torch = env
+    enc = ta.capi.encode_nodes
+    nodes = enc(fid=[0, 1, 0, 0, 0, 1, 1], value=[0.5, -1.0, 10.0, 1.0, 2.0, 77.0, 88.0],
+                def_left=[1, 0, 0, 0, 0, 0, 0], weight=[0] * 7, is_leaf=[0, 0, 1, 1, 1, 0, 0])
+    data = np.array([[0.5, 0.0],      # tie at node0 -> right -> leaf node2
+                     [0.4, -1.0],     # left; tie at node1 -> right -> node4
+                     [0.4, -1.5],     # left; left -> node3
+                     [MISSING, 5.0],  # missing at node0, def_left -> left; node1 right -> node4
+                     [0.0, MISSING],  # left; missing at node1, def_left=0 -> right -> node4
+                     [np.nan, np.nan]], dtype=np.float32)  # NaN fails >= -> left, left -> node3
+    want_leaf = np.array([[2], [4], [3], [4], [4], [3]], dtype=np.uint32)
+    want = np.array([10.0, 2.0, 1.0, 2.0, 2.0, 1.0], dtype=np.float32)
+    o_pred, o_leaf = oracle.predict(nodes, 1, 2, data, MISSING, want_leaf=True)
+    assert np.array_equal(o_leaf, want_leaf) and np.array_equal(o_pred, want)
+    got, got_leaf = run_case(env, nodes, 1, 2, 2, data)
+    assert np.array_equal(got_leaf, want_leaf) and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("output,threshold,bias", [
+    (0x1, 0.0, 0.0), (0x0, 0.0, 0.75), (0x1, 0.0, -0.5), (0x10, 0.0, 0.0), (0x11, 0.0, 0.1),
+    (0x100, 0.3, 0.0), (0x101, 0.01, 0.0), (0x111, 0.5, 0.05),
+])
+def test_output_transforms(env, output, threshold, bias):
+    ta, oracle, torch = env
+    T, D, C, R = 37, 5, 20, 999
+    nodes = ta.synth_forest(T, D, C, seed=21)
+    data = ta.synth_data(R, C, seed=22, missing_prob=0.02, missing=MISSING)
+    want, _ = oracle.predict(nodes, T, D, data, MISSING, output=output, threshold=threshold, global_bias=bias)
+    forest = ta.Forest(nodes, T, D, C, missing=MISSING, output=output, threshold=threshold, global_bias=bias)
+    got = forest.predict(torch.from_numpy(data).cuda()).cpu().numpy()
+    if output & 0x10 and not output & 0x100:
+        # sigmoid: device expf vs glibc expf, tolerance 1e-6 relative
+        np.testing.assert_allclose(got, want, rtol=1e-6, atol=0)
+    elif output & 0x10:
+        # thresholded sigmoid: may only differ where the sigmoid is within 1e-6 relative of the threshold
+        raw, _ = oracle.predict(nodes, T, D, data, MISSING, output=output & ~0x100, global_bias=bias)
+        differ = got != want
+        assert np.all(np.abs(raw[differ] - threshold) <= 1e-6 * abs(threshold))
+    else:
+        assert np.array_equal(bits(got), bits(want))
+
+
+def test_empty_and_degenerate(env):
+    ta, oracle, torch = env
+    nodes = ta.synth_forest(3, 2, 4, seed=1)
+    forest = ta.Forest(nodes, 3, 2, 4, missing=MISSING)
+    empty = torch.empty((0, 4), dtype=torch.float32, device="cuda")
+    assert forest.predict(empty).numel() == 0
+    leaf, sums = forest.predict_leaf_idx(empty)
+    assert leaf.shape == (0, 3)
+    # a forest with no trees predicts 0 (+ bias) for every row
+    f0 = ta.Forest(np.empty(0, dtype=ta.NODE_DTYPE), 0, 3, 4, missing=MISSING, global_bias=0.5)
+    x = torch.from_numpy(ta.synth_data(10, 4, seed=2)).cuda()
+    assert np.array_equal(f0.predict(x).cpu().numpy(), np.full(10, 0.5, dtype=np.float32))
+
+
+def test_invalid_forests_are_rejected(env):
+    ta = env[0]
+    enc = ta.capi.encode_nodes
+    # reachable bottom-level node that is not a leaf: the reference would walk out of the tree
+    nodes = enc([0, 0, 0], [0.0, 1.0, 2.0], [0, 0, 0], [0, 0, 0], [0, 1, 0])
+    with pytest.raises(ta.TahoeError) as e:
+        ta.Forest(nodes, 1, 1, 1)
+    assert e.value.status == 6
+    # fid out of range
+    nodes = enc([5, 0, 0], [0.0, 1.0, 2.0], [0, 0, 0], [0, 0, 0], [0, 1, 1])
+    with pytest.raises(ta.TahoeError) as e:
+        ta.Forest(nodes, 1, 1, 3)
+    assert e.value.status == 6
+    # ROWTILE cannot hold a 3072-column tile
+    f = ta.Forest(ta.synth_forest(2, 3, 3072, seed=3), 2, 3, 3072)
+    with pytest.raises(ta.TahoeError) as e:
+        f.set_strategy(ta.STRATEGY_ROWTILE)
+    assert e.value.status == 7
+    assert f.get_strategy(100) == ta.STRATEGY_DIRECT
+
+
+def test_golden_fixtures(env):
+    """Committed model/data text files -> expected sums and leaf indices (tests/golden/README.md)."""
+    import glob
+    import os
+
+    ta, oracle, torch = env
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    cases = sorted(glob.glob(os.path.join(here, "*.model.txt")))
+    assert cases, "no golden fixtures"
+    for model in cases:
+        stem = model[: -len(".model.txt")]
+        nodes, T, D = ta.load_model(model)
+        data, missing = ta.load_data(stem + ".data.txt")
+        exp = np.load(stem + ".expected.npz")
+        forest = ta.Forest(nodes, T, D, data.shape[1], missing=missing)
+        for s in (ta.STRATEGY_DIRECT, ta.STRATEGY_AUTO):
+            forest.set_strategy(s)
+            leaf, sums = forest.predict_leaf_idx(torch.from_numpy(data).cuda())
+            assert np.array_equal(bits(leaf.cpu().numpy()), exp["leaf_idx"]), stem
+            assert np.array_equal(bits(sums.cpu().numpy()), exp["sums_bits"]), stem
+
+
+def test_k3_full_size_properties(env):
+    """BASELINE config 3 at full size (1000 trees, depth 12, 256 features, 1M rows): oracle on a strided
+    sample of rows, and size-independent properties on all rows."""
+    ta, oracle, torch = env
+    T, D, C, R = 1000, 12, 256, 1_000_000
+    nodes = ta.synth_forest(T, D, C, seed=42)
+    data = ta.synth_data(R, C, seed=43)
+    x = torch.from_numpy(data).cuda()
+    forest = ta.Forest(nodes, T, D, C, missing=MISSING)
+    sums = forest.predict_raw(x)
+    torch.cuda.synchronize()
+    got = sums.cpu().numpy()
+    # (1) oracle on 1500 strided rows (first, last, ragged tail of the last 64-row tile included)
+    idx = np.unique(np.concatenate([np.arange(0, R, 997), [R - 1, R - 2, R - 63, R - 64, R - 65]]))[:1500]
+    want, want_leaf = oracle.predict(nodes, T, D, data[idx], MISSING, want_leaf=True, threads=8)
+    assert np.array_equal(bits(got[idx]), bits(want))
+    leaf, _ = forest.predict_leaf_idx(x[torch.from_numpy(idx).cuda()].contiguous(), want_sums=False)
+    assert np.array_equal(bits(leaf.cpu().numpy()), want_leaf)
+    # (2) two independent kernels agree on every row
+    forest.set_strategy(ta.STRATEGY_DIRECT)
+    d_sums = forest.predict_raw(x[: 200_000].contiguous()).cpu().numpy()
+    assert np.array_equal(bits(d_sums), bits(got[:200_000]))
+    forest.set_strategy(ta.STRATEGY_AUTO)
+    # (3) row-permutation equivariance: predict(x[perm]) == predict(x)[perm]
+    perm = torch.randperm(R, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    p_sums = forest.predict_raw(x[perm].contiguous()).cpu().numpy()
+    assert np.array_equal(bits(p_sums), bits(got[perm.cpu().numpy()]))
+    # (4) a ragged batch (not a multiple of the 64-row tile) matches the prefix of the full batch
+    r_sums = forest.predict_raw(x[: 100_003].contiguous()).cpu().numpy()
+    assert np.array_equal(bits(r_sums), bits(got[:100_003]))
