@@ -20,6 +20,14 @@ if not os.path.exists(LIB_PATH):
         "or `make -C tahoe_amd/csrc`.  tahoe_amd has no fallback path."
     )
 
+# torch bundles its own libamdhip64.so.7.  Two HIP runtimes in one process do not share a device
+# context (the second one sees no GPU), so load torch's first: libtahoe_amd.so then binds to the
+# already-loaded runtime by SONAME.  Without torch (the C++ CLI) the system runtime is used.
+try:
+    import torch  # noqa: F401
+except ImportError:  # pragma: no cover
+    pass
+
 lib = C.CDLL(LIB_PATH)
 
 # ---- constants mirrored from the header ----
