@@ -89,8 +89,13 @@ enum {
     TAHOE_STRATEGY_AUTO = 0,     /* selector picks from shape and LDS capacity */
     TAHOE_STRATEGY_DIRECT = 1,   /* lane = row, nodes and features straight from global memory
                                     (analogue of infer_adaptive_reorg_*, Struct.h:1196-1240) */
-    TAHOE_STRATEGY_ROWTILE = 2   /* 64-row feature-major tile in LDS, waves split the trees, top
-                                    levels of each tree staged in LDS, ordered leaf-sum exchange */
+    TAHOE_STRATEGY_ROWTILE = 2,  /* 64-row feature-major tile in LDS, waves split the trees, top 8
+                                    levels of each tree staged in LDS, deeper levels gathered from
+                                    global memory, ordered leaf-sum exchange; any num_cols whose
+                                    tile fits LDS */
+    TAHOE_STRATEGY_TILEBLOCK = 3 /* num_cols <= 512: 128- (or 64-) row tile in LDS, four trees in
+                                    flight, top 10 levels SoA in LDS, last two levels + leaves from
+                                    one 32-byte block per walk */
 };
 
 typedef struct tahoe_forest tahoe_forest; /* opaque */
@@ -135,9 +140,12 @@ typedef struct {
     int lds_levels;          /* top levels staged in LDS by ROWTILE */
     size_t device_bytes;     /* device memory owned by the handle */
     size_t path_len_sum;     /* sum over trees of ... (reserved) */
-    int lds_bytes_per_block; /* dynamic LDS of the ROWTILE kernel */
+    int lds_bytes_per_block; /* dynamic LDS of the ROWTILE kernel (0 = does not fit) */
     int device_id;
     int num_cus;
+    int top_levels;          /* top levels staged in LDS by TILEBLOCK */
+    int tile_rows;           /* rows per TILEBLOCK tile: 128, 64, or 0 = strategy unavailable */
+    int tileblock_lds_bytes; /* dynamic LDS of the TILEBLOCK kernel */
 } tahoe_forest_info;
 tahoe_status tahoe_forest_get_info(const tahoe_forest *f, tahoe_forest_info *info);
 

@@ -22,4 +22,5 @@ from .capi import (  # noqa: F401
     STRATEGY_AUTO,
     STRATEGY_DIRECT,
     STRATEGY_ROWTILE,
+    STRATEGY_TILEBLOCK,
 )

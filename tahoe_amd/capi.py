@@ -32,7 +32,7 @@ lib = C.CDLL(LIB_PATH)
 
 # ---- constants mirrored from the header ----
 OUT_RAW, OUT_AVG, OUT_SIGMOID, OUT_THRESHOLD = 0x0, 0x1, 0x10, 0x100
-STRATEGY_AUTO, STRATEGY_DIRECT, STRATEGY_ROWTILE = 0, 1, 2
+STRATEGY_AUTO, STRATEGY_DIRECT, STRATEGY_ROWTILE, STRATEGY_TILEBLOCK = 0, 1, 2, 3
 STATUS_NAMES = {
     0: "TAHOE_OK",
     1: "TAHOE_ERR_INVALID_ARG",
@@ -77,6 +77,9 @@ class ForestInfo(C.Structure):
         ("lds_bytes_per_block", C.c_int),
         ("device_id", C.c_int),
         ("num_cus", C.c_int),
+        ("top_levels", C.c_int),
+        ("tile_rows", C.c_int),
+        ("tileblock_lds_bytes", C.c_int),
     ]
 
 

@@ -4,18 +4,22 @@
 //   dense_forest / dense_adaptive_forest  (init, infer, predict)     Struct.h:802-861, :1710-2210
 //   the walkers infer_one_tree_* and kernels infer_k_* / infer_adaptive_reorg_*   Struct.h:359-1704
 //   cub::BlockReduce / DeviceSegmentedReduce call sites (table 2b of SURVEY.md)  -> ordered
-//     per-row accumulation (no tree-parallel float reduction, see "sum order" below)
+//     per-row accumulation through LDS (no tree-parallel float reduction, see "sum order")
 //   transform_k                                                      Struct.h:196-209
 //
-// Device layout ("perfect-tree" SoA-of-records, built once at create):
-//   Every tree is normalised to a perfect binary tree of depth D: a leaf found above the bottom
-//   level is pushed down -- all bottom-level descendants inherit its value and remember its
-//   original heap index.  A walk is then exactly D compare-and-step iterations with no leaf test,
-//   so all 64 lanes of a wave stay converged, and the per-(row,tree) result is one gather from
-//   the bottom array.  Per tree t:
-//     inner[t][2^D - 1]  {float thr; uint32 meta}   meta = fid | def_left << 31   (heap order)
-//     leaf_val[t][2^D]   float
-//     leaf_orig[t][2^D]  uint32  original heap index of the leaf (for predict_leaf_idx)
+// Device layout, built once at create ("perfect-tree" normalisation):
+//   Every tree is normalised to a perfect binary tree of depth De = max(depth, 2): a leaf found
+//   above the bottom level is pushed down -- all bottom-level descendants inherit its value and
+//   remember its original heap index.  A walk is then exactly De compare-and-step iterations with
+//   no leaf test, so the 64 lanes of a wave never diverge.  Three views of the same tree t:
+//     (1) heap records          inner[t][2^De - 1] {float thr; uint32 meta}, meta = fid | def_left<<31
+//                               leaf_val[t][2^De] float, leaf_orig[t][2^De] uint32 (original heap index)
+//     (2) top, SoA (<=10 levels) top[t]: thr[2^L] float | meta[2^L] uint16 (fid | def_left<<15), indexed by
+//                               1-based heap position: staged whole into LDS by the TILEBLOCK kernel
+//     (3) bottom blocks          blk[t][2^(De-2)] 32 B: {thr0, thr1, thr2, 3 x (fid:9 | def_left:1)} {leaf0..3}
+//                               = the subtree of the last two inner levels and its four leaves, fetched
+//                               with two 16-byte gathers that share one cache line
+//   Views (2) and (3) exist when num_cols <= 512 (9-bit feature ids).
 //
 // Sum order: the CPU predictor adds leaf values in tree order 0..T-1 in float32
 // (BaseTahoeTest.h:462-466).  Every kernel here adds them in exactly that order per row, so the raw
@@ -24,6 +28,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -38,28 +43,48 @@ struct InnerNode {
 };
 static_assert(sizeof(InnerNode) == 8, "InnerNode must be 8 bytes");
 
-constexpr int kBlock = 256;        // threads per workgroup (4 waves)
+constexpr int kBlock = 256;             // threads per workgroup of DIRECT / ROWTILE (4 waves)
 constexpr int kWaves = kBlock / 64;
-constexpr int kTileRows = 64;      // rows per ROWTILE workgroup = one wave of lanes
-constexpr int kMaxLdsLevels = 8;   // top levels of a tree staged per wave (255 nodes = 2040 B)
+constexpr int kTileRows = 64;           // rows per ROWTILE workgroup = one wave of lanes
+constexpr int kMaxLdsLevels = 8;        // ROWTILE: top levels staged per wave (255 nodes = 2040 B)
 constexpr float kMissingEps = 1.0e-6f;  // BaseTahoeTest.h:451
+
+// TILEBLOCK geometry
+constexpr int kTopLevelsMax = 10;       // top levels kept in LDS (1023 nodes: 4 KiB thr + 2 KiB meta)
+constexpr int kSlots = 4;               // trees in flight per workgroup
+constexpr int kBlockFidBits = 9;        // bottom blocks pack 3 x (fid:9 | def_left:1) in one dword
+constexpr int kBlockMaxCols = 1 << kBlockFidBits;
+
+static inline int align16(int x) { return (x + 15) & ~15; }
+static inline int top_nodes(int top_levels) { return (1 << top_levels) - 1; }
+// A staged top is indexed by 1-based heap position (entry 0 unused), so that the two children of
+// position i form the aligned pair (2i, 2i+1).
+static inline int top_thr_bytes(int top_levels) { return align16((top_nodes(top_levels) + 1) * 4); }
+static inline int top_stride_bytes(int top_levels)
+{
+    return top_thr_bytes(top_levels) + align16((top_nodes(top_levels) + 1) * 2);
+}
 
 }  // namespace tahoe
 
 struct tahoe_forest {
     tahoe_forest_params p{};
-    int depth = 0;
-    size_t n_inner = 0;  // 2^D - 1
-    size_t n_leaf = 0;   // 2^D
+    int depth = 0;        // De: depth of the normalised trees, max(p.depth, 2)
+    size_t n_inner = 0;   // 2^De - 1
+    size_t n_leaf = 0;    // 2^De
     int bits_bytes = 0;
     int strategy = TAHOE_STRATEGY_AUTO;
     int device = 0;
     int num_cus = 0;
     int lds_limit = 0;
-    int lds_levels = 0;
+    int lds_levels = 0;   // ROWTILE
+    int top_levels = 0;   // TILEBLOCK: levels in LDS, min(De - 2, 10)
+    bool has_blocks = false;
     tahoe::InnerNode *inner = nullptr;
     float *leaf_val = nullptr;
     uint32_t *leaf_orig = nullptr;
+    unsigned char *top = nullptr;  // [T][top_stride]
+    uint4 *blocks = nullptr;       // [T][2^(De-2)][2]
     size_t device_bytes = 0;
     // Profiling: one hipEvent pair per traversal launch, read back after the stream has drained.
     bool profiling = false;
@@ -70,13 +95,16 @@ struct tahoe_forest {
 namespace tahoe {
 
 // ------------------------------------------------------------------------------------------------
-// One compare-and-step: the branch rule of infer_one_tree, BaseTahoeTest.h:450-453.
-__device__ __forceinline__ uint32_t step(uint32_t idx, float thr, uint32_t meta, float x, float missing)
+// The branch rule of infer_one_tree, BaseTahoeTest.h:450-453: 1 = right child.
+__device__ __forceinline__ uint32_t go_right(float x, float thr, bool def_left, float missing)
 {
-    const bool def_left = (meta >> 31) != 0;
     const bool is_missing = fabsf(x - missing) <= kMissingEps;
     const bool cond = is_missing ? !def_left : (x >= thr);
-    return 2u * idx + 1u + (cond ? 1u : 0u);
+    return cond ? 1u : 0u;
+}
+__device__ __forceinline__ uint32_t step(uint32_t idx, float thr, uint32_t meta, float x, float missing)
+{
+    return 2u * idx + 1u + go_right(x, thr, (meta >> 31) != 0, missing);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -116,7 +144,7 @@ __global__ void __launch_bounds__(kBlock) direct_kernel(const InnerNode *__restr
 // (wave w walks trees w, w+4, ...); each wave stages the top `lds_levels` levels of its current
 // tree in a private LDS slot (prefetched into registers during the previous walk) and reads deeper
 // levels from global memory.  Leaf values are exchanged through LDS once per round of four trees and
-// added by the row's owner lane in tree order.
+// added by the row's owner lane in tree order.  Any num_cols whose 64-row tile fits LDS.
 //
 // Dynamic LDS: [cols][64] float | kWaves slots of slot_nodes InnerNode | [2][kWaves][64] float.
 template <bool WRITE_LEAF>
@@ -228,6 +256,188 @@ __global__ void __launch_bounds__(kBlock) rowtile_kernel(const InnerNode *__rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// TILEBLOCK: the K3-shaped strategy (num_cols <= 512).
+//   * ROWS (128 or 64) rows of the batch live feature-major in LDS for the whole kernel.
+//   * kSlots = 4 trees are in flight; slot s is walked by ROWS/64 waves (one per 64-row group).
+//     A slot holds the tree's top `top_levels` levels as SoA (thr float | meta uint16): one
+//     ds_read_b32 + one ds_read_u16 per visit, feature read conflict-free by layout.
+//   * Levels below the LDS top and above the last two come from the heap records in global memory
+//     (only when De > 12); the last two levels and the leaves come from one 32-byte block.
+//   * The next round's tops are prefetched into registers while the current trees are walked and
+//     committed to LDS between the two barriers of a round; leaf values cross LDS once per round
+//     and are added by the row's owner lane in tree order (bit-exact float32 sums).
+// Dynamic LDS: [cols][ROWS] float | kSlots x top_stride bytes | [2][kSlots][ROWS] float.
+template <int ROWS, bool WRITE_LEAF>
+__global__ void __launch_bounds__(kSlots *ROWS)
+    tileblock_kernel(const unsigned char *__restrict__ top, const uint4 *__restrict__ blocks,
+                     const InnerNode *__restrict__ inner, const uint32_t *__restrict__ leaf_orig,
+                     const float *__restrict__ data, float *__restrict__ sums, uint32_t *__restrict__ leaf_out,
+                     size_t rows, int cols, int num_trees, int depth, int top_levels, int top_stride, float missing,
+                     int vec4_ok)
+{
+    constexpr int RG = ROWS / 64;            // waves per slot (row groups)
+    constexpr int NT = kSlots * ROWS;        // threads
+    constexpr int NW = NT / 64;              // waves
+    constexpr int OWN = ROWS / NW;           // rows each wave accumulates (16)
+    constexpr int kChunksMax = (4096 + 2048) / 16;
+    constexpr int PF = (kChunksMax + ROWS - 1) / ROWS;  // 16-byte chunks a lane prefetches (3 or 6)
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: wave-uniform branches below
+    const int slot_id = wave / RG;
+    const int rgrp = wave % RG;
+    const int rloc = rgrp * 64 + lane;       // row within the tile
+    const int sl = rgrp * 64 + lane;         // lane index within the slot's group of RG waves
+
+    float *tile = reinterpret_cast<float *>(smem);
+    unsigned char *slots = smem + (size_t)cols * ROWS * sizeof(float);
+    float *vals = reinterpret_cast<float *>(slots + (size_t)kSlots * top_stride);
+    unsigned char *slot = slots + (size_t)slot_id * top_stride;
+    // slot = thr[2^L] float | meta[2^L] uint16, both indexed by 1-based heap position (entry 0 unused)
+    const float *s_thr = reinterpret_cast<const float *>(slot);
+    const uint16_t *s_meta = reinterpret_cast<const uint16_t *>(slot + (((4 << top_levels) + 15) & ~15));
+    const int n_chunks = top_stride >> 4;
+
+    const size_t row0 = (size_t)blockIdx.x * ROWS;
+    const size_t row = row0 + rloc;
+    const bool row_ok = row < rows;
+
+    // ---- stage the row tile, transposed to feature-major (conflict-free: bank = row % 32) ----
+    {
+        const int trow = tid % ROWS, tpart = tid / ROWS;  // kSlots parts stride over the features
+        const size_t grow = row0 + trow;
+        const bool ok = grow < rows;
+        const float *src = data + (ok ? grow : row0) * (size_t)cols;
+        if (vec4_ok) {
+            const float4 *src4 = reinterpret_cast<const float4 *>(src);
+            for (int f4 = tpart; f4 < cols / 4; f4 += kSlots) {
+                const float4 v = ok ? src4[f4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                tile[(4 * f4 + 0) * ROWS + trow] = v.x;
+                tile[(4 * f4 + 1) * ROWS + trow] = v.y;
+                tile[(4 * f4 + 2) * ROWS + trow] = v.z;
+                tile[(4 * f4 + 3) * ROWS + trow] = v.w;
+            }
+        } else {
+            for (int f = tpart; f < cols; f += kSlots) tile[f * ROWS + trow] = ok ? src[f] : 0.0f;
+        }
+    }
+
+    // Next round's top: PF 16-byte chunks per lane, held in registers while the current tree is walked.
+    // Named registers (not an array): an indexed array ends up in scratch memory.
+    uint4 pf0 = {}, pf1 = {}, pf2 = {}, pf3 = {}, pf4 = {}, pf5 = {};
+    static_assert(PF == 3 || PF == 6, "prefetch registers are written out for 3 or 6 chunks per lane");
+    auto prefetch_top = [&](int t) {
+        const uint4 *g = reinterpret_cast<const uint4 *>(top + (size_t)t * top_stride);
+        const int last = n_chunks - 1;  // clamped: branch-free and in bounds
+        pf0 = g[min(0 * ROWS + sl, last)];
+        pf1 = g[min(1 * ROWS + sl, last)];
+        pf2 = g[min(2 * ROWS + sl, last)];
+        if constexpr (PF == 6) {
+            pf3 = g[min(3 * ROWS + sl, last)];
+            pf4 = g[min(4 * ROWS + sl, last)];
+            pf5 = g[min(5 * ROWS + sl, last)];
+        }
+    };
+    auto commit_top = [&]() {
+        uint4 *s = reinterpret_cast<uint4 *>(slot);
+        if (0 * ROWS + sl < n_chunks) s[0 * ROWS + sl] = pf0;
+        if (1 * ROWS + sl < n_chunks) s[1 * ROWS + sl] = pf1;
+        if (2 * ROWS + sl < n_chunks) s[2 * ROWS + sl] = pf2;
+        if constexpr (PF == 6) {
+            if (3 * ROWS + sl < n_chunks) s[3 * ROWS + sl] = pf3;
+            if (4 * ROWS + sl < n_chunks) s[4 * ROWS + sl] = pf4;
+            if (5 * ROWS + sl < n_chunks) s[5 * ROWS + sl] = pf5;
+        }
+    };
+    if (slot_id < num_trees) {
+        prefetch_top(slot_id);
+        commit_top();
+    }
+    __syncthreads();
+
+    const size_t n_inner = ((size_t)1 << depth) - 1;
+    const uint32_t n_blocks = 1u << (depth - 2);
+    const uint32_t first_block_node = n_blocks - 1;  // heap index of the first node of level depth-2
+    float sum = 0.0f;                                // lanes 0..OWN-1: row OWN*wave + lane of the tile
+    const int rounds = (num_trees + kSlots - 1) / kSlots;
+    for (int r = 0; r < rounds; ++r) {
+        const int t = r * kSlots + slot_id;
+        const bool more = t + kSlots < num_trees;
+        float v = 0.0f;
+        if (t < num_trees) {
+            if (more) prefetch_top(t + kSlots);
+            // Top levels from LDS, 1-based heap positions: the children of position i are the aligned
+            // pair (2i, 2i+1), read together with the current node's feature -> one LDS round trip
+            // per level.
+            uint32_t i = 1;
+            if (top_levels > 0) {
+                float thr = s_thr[1];
+                uint32_t m = s_meta[1];
+                for (int l = 0; l < top_levels - 1; ++l) {
+                    const float x = tile[(m & 0x7fffu) * ROWS + rloc];
+                    const float2 t2 = *reinterpret_cast<const float2 *>(&s_thr[2 * i]);
+                    const uint32_t m2 = *reinterpret_cast<const uint32_t *>(&s_meta[2 * i]);
+                    const uint32_t c = go_right(x, thr, (m >> 15) != 0, missing);
+                    i = 2u * i + c;
+                    thr = c ? t2.y : t2.x;
+                    m = c ? (m2 >> 16) : (m2 & 0xffffu);
+                }
+                const float x = tile[(m & 0x7fffu) * ROWS + rloc];
+                i = 2u * i + go_right(x, thr, (m >> 15) != 0, missing);
+            }
+            uint32_t idx = i - 1;  // 0-based heap index on level top_levels
+            if (top_levels < depth - 2) {  // deep trees only (De > 12): heap records from global memory
+                const InnerNode *tree = inner + (size_t)t * n_inner;
+                for (int l = top_levels; l < depth - 2; ++l) {
+                    const InnerNode n = tree[idx];
+                    const float x = tile[(n.meta & 0x7fffffffu) * ROWS + rloc];
+                    idx = step(idx, n.thr, n.meta, x, missing);
+                }
+            }
+            const uint32_t b = idx - first_block_node;
+            const uint4 *bp = blocks + ((size_t)t * n_blocks + b) * 2;
+            const uint4 na = bp[0];  // thr0, thr1, thr2, packed metas
+            const uint4 nb = bp[1];  // four leaf values
+            // Both 16-byte loads are issued here, whole: without the pins the compiler sinks single
+            // dwords of them into the branches of go_right and pays a second global round trip.
+            asm volatile("" ::"v"(na.x), "v"(na.y), "v"(na.z), "v"(na.w));
+            asm volatile("" ::"v"(nb.x), "v"(nb.y), "v"(nb.z), "v"(nb.w));
+            const uint32_t m = na.w;
+            const float x0 = tile[(m & 0x1ffu) * ROWS + rloc];
+            const float x1 = tile[((m >> 10) & 0x1ffu) * ROWS + rloc];
+            const float x2 = tile[((m >> 20) & 0x1ffu) * ROWS + rloc];
+            const uint32_t c0 = go_right(x0, __uint_as_float(na.x), ((m >> 9) & 1u) != 0, missing);
+            const uint32_t c1l = go_right(x1, __uint_as_float(na.y), ((m >> 19) & 1u) != 0, missing);
+            const uint32_t c1r = go_right(x2, __uint_as_float(na.z), ((m >> 29) & 1u) != 0, missing);
+            const uint32_t c1 = c0 ? c1r : c1l;
+            const uint32_t lo = c1 ? nb.y : nb.x, hi = c1 ? nb.w : nb.z;
+            v = __uint_as_float(c0 ? hi : lo);
+            if (WRITE_LEAF) {
+                if (row_ok)
+                    leaf_out[row * (size_t)num_trees + t] =
+                        leaf_orig[(size_t)t * ((size_t)n_blocks * 4) + (size_t)b * 4 + 2 * c0 + c1];
+            }
+        }
+        float *vb = vals + (size_t)(r & 1) * kSlots * ROWS;
+        vb[slot_id * ROWS + rloc] = v;
+        __syncthreads();  // (A) every walk of this round has finished reading its slot
+        if (t < num_trees && more) commit_top();
+        if (lane < OWN) {
+            const int rr = OWN * wave + lane;
+            const int nt = min(kSlots, num_trees - r * kSlots);
+            for (int j = 0; j < nt; ++j) sum += vb[j * ROWS + rr];  // tree order
+        }
+        __syncthreads();  // (B) the next round's tops are in LDS
+    }
+    if (sums && lane < OWN) {
+        const size_t orow = row0 + OWN * wave + lane;
+        if (orow < rows) sums[orow] = sum;
+    }
+}
+
 // transform_k (Struct.h:196-209) with the CPU predictor's arithmetic (BaseTahoeTest.h:467-472):
 // AVG divides by num_trees (the reference's GPU epilogue multiplies by 1/T instead).
 __global__ void transform_kernel(float *preds, size_t n, int output, int num_trees, float threshold,
@@ -257,10 +467,47 @@ static bool rowtile_fits(const tahoe_forest *f)
     return f->p.num_cols >= 1 && (long long)rowtile_lds_bytes(f->p.num_cols, f->lds_levels) <= f->lds_limit;
 }
 
+static long long tileblock_lds_bytes(const tahoe_forest *f, int tile_rows)
+{
+    return (long long)f->p.num_cols * tile_rows * 4 + (long long)kSlots * top_stride_bytes(f->top_levels) +
+           2LL * kSlots * tile_rows * 4;
+}
+
+// Rows per TILEBLOCK tile: 128 when it fits LDS, else 64, else 0 (strategy unavailable).
+static int tileblock_rows(const tahoe_forest *f)
+{
+    if (!f->has_blocks || f->p.num_cols < 1) return 0;
+    if (const char *e = getenv("TAHOE_TILE_ROWS")) {  // tuning knob for experiments
+        const int r = atoi(e);
+        if ((r == 64 || r == 128) && tileblock_lds_bytes(f, r) <= f->lds_limit) return r;
+    }
+    if (tileblock_lds_bytes(f, 128) <= f->lds_limit) return 128;
+    if (tileblock_lds_bytes(f, 64) <= f->lds_limit) return 64;
+    return 0;
+}
+
 static int resolve_strategy(const tahoe_forest *f, size_t /*rows*/)
 {
     if (f->strategy != TAHOE_STRATEGY_AUTO) return f->strategy;
+    if (tileblock_rows(f) > 0) return TAHOE_STRATEGY_TILEBLOCK;
     return rowtile_fits(f) ? TAHOE_STRATEGY_ROWTILE : TAHOE_STRATEGY_DIRECT;
+}
+
+template <int ROWS>
+static void launch_tileblock(tahoe_forest *f, float *sums, uint32_t *leaf_out, const float *data, size_t rows,
+                             hipStream_t stream, int vec4_ok)
+{
+    const unsigned grid = (unsigned)((rows + ROWS - 1) / ROWS);
+    const int lds = (int)tileblock_lds_bytes(f, ROWS);
+    const int stride = top_stride_bytes(f->top_levels);
+    if (leaf_out)
+        hipLaunchKernelGGL((tileblock_kernel<ROWS, true>), dim3(grid), dim3(kSlots * ROWS), lds, stream, f->top,
+                           f->blocks, f->inner, f->leaf_orig, data, sums, leaf_out, rows, f->p.num_cols,
+                           f->p.num_trees, f->depth, f->top_levels, stride, f->p.missing, vec4_ok);
+    else
+        hipLaunchKernelGGL((tileblock_kernel<ROWS, false>), dim3(grid), dim3(kSlots * ROWS), lds, stream, f->top,
+                           f->blocks, f->inner, f->leaf_orig, data, sums, leaf_out, rows, f->p.num_cols,
+                           f->p.num_trees, f->depth, f->top_levels, stride, f->p.missing, vec4_ok);
 }
 
 static tahoe_status launch_traversal(tahoe_forest *f, float *sums, uint32_t *leaf_out, const float *data,
@@ -268,19 +515,29 @@ static tahoe_status launch_traversal(tahoe_forest *f, float *sums, uint32_t *lea
 {
     if (rows == 0) return TAHOE_OK;
     const int strategy = resolve_strategy(f, rows);
+    if ((rows + 63) / 64 > 0x7fffffffu) return fail(TAHOE_ERR_INVALID_ARG, "too many rows for one launch: %zu", rows);
     const bool timed = f->profiling && f->prof_count < f->ev_start.size();
     if (timed) TAHOE_HIP_TRY(hipEventRecord(f->ev_start[f->prof_count], stream));
+    const int vec4_ok = (f->p.num_cols % 4 == 0) && ((reinterpret_cast<uintptr_t>(data) & 15u) == 0);
     if (f->p.num_trees == 0) {
         // Nothing to walk: sums are zero (an empty j-loop in predict_on_cpu).
         if (sums) TAHOE_HIP_TRY(hipMemsetAsync(sums, 0, rows * sizeof(float), stream));
+    } else if (strategy == TAHOE_STRATEGY_TILEBLOCK) {
+        const int tr = tileblock_rows(f);
+        if (tr == 0)
+            return fail(TAHOE_ERR_UNSUPPORTED, "TILEBLOCK needs num_cols <= %d and a 64-row tile that fits %d B of LDS",
+                        kBlockMaxCols, f->lds_limit);
+        if (tr == 128)
+            launch_tileblock<128>(f, sums, leaf_out, data, rows, stream, vec4_ok);
+        else
+            launch_tileblock<64>(f, sums, leaf_out, data, rows, stream, vec4_ok);
+        TAHOE_HIP_TRY(hipGetLastError());
     } else if (strategy == TAHOE_STRATEGY_ROWTILE) {
         if (!rowtile_fits(f))
             return fail(TAHOE_ERR_UNSUPPORTED, "ROWTILE needs %d B of LDS for %d columns; device offers %d",
                         rowtile_lds_bytes(f->p.num_cols, f->lds_levels), f->p.num_cols, f->lds_limit);
         const size_t grid = (rows + kTileRows - 1) / kTileRows;
-        if (grid > 0x7fffffffu) return fail(TAHOE_ERR_INVALID_ARG, "too many rows for one launch: %zu", rows);
         const int lds = rowtile_lds_bytes(f->p.num_cols, f->lds_levels);
-        const int vec4_ok = (f->p.num_cols % 4 == 0) && ((reinterpret_cast<uintptr_t>(data) & 15u) == 0);
         if (leaf_out)
             hipLaunchKernelGGL(rowtile_kernel<true>, dim3((unsigned)grid), dim3(kBlock), lds, stream, f->inner,
                                f->leaf_val, f->leaf_orig, data, sums, leaf_out, rows, f->p.num_cols,
@@ -292,7 +549,6 @@ static tahoe_status launch_traversal(tahoe_forest *f, float *sums, uint32_t *lea
         TAHOE_HIP_TRY(hipGetLastError());
     } else if (strategy == TAHOE_STRATEGY_DIRECT) {
         const size_t grid = (rows + kBlock - 1) / kBlock;
-        if (grid > 0x7fffffffu) return fail(TAHOE_ERR_INVALID_ARG, "too many rows for one launch: %zu", rows);
         if (leaf_out)
             hipLaunchKernelGGL(direct_kernel<true>, dim3((unsigned)grid), dim3(kBlock), 0, stream, f->inner,
                                f->leaf_val, f->leaf_orig, data, sums, leaf_out, rows, f->p.num_cols,
@@ -332,6 +588,24 @@ static int reference_bits_bytes(int max_fid)
     return len == 0 ? 1 : (len == 1 ? 2 : 4);
 }
 
+template <typename T>
+static hipError_t upload(T **dst, const std::vector<T> &src, size_t *total)
+{
+    const size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(dst), bytes);
+    if (e != hipSuccess) return e;
+    *total += bytes;
+    if (!src.empty()) e = hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice);
+    return e;
+}
+
+template <typename K>
+static hipError_t allow_lds(K kernel, long long bytes)
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)bytes);
+}
+
 }  // namespace tahoe
 
 using namespace tahoe;
@@ -362,53 +636,67 @@ tahoe_status tahoe_forest_create(tahoe_forest **out, const tahoe_dense_node *nod
 
     tahoe_forest *f = new (std::nothrow) tahoe_forest();
     if (!f) return fail(TAHOE_ERR_NO_MEMORY, "tahoe_forest_create");
+    const int D = p->depth;             // depth of the trees as given
+    const int De = std::max(D, 2);      // depth of the normalised trees
     f->p = *p;
-    f->depth = p->depth;
-    f->n_inner = ((size_t)1 << p->depth) - 1;
-    f->n_leaf = (size_t)1 << p->depth;
+    f->depth = De;
+    f->n_inner = ((size_t)1 << De) - 1;
+    f->n_leaf = (size_t)1 << De;
     f->device = dev;
     f->num_cus = prop.multiProcessorCount;
     f->lds_limit = (int)prop.maxSharedMemoryPerMultiProcessor > 0 ? (int)prop.maxSharedMemoryPerMultiProcessor
                                                                    : (int)prop.sharedMemPerBlock;
-    f->lds_levels = std::min(p->depth, kMaxLdsLevels);
+    f->lds_levels = std::min(De, kMaxLdsLevels);
+    f->top_levels = std::min(De - 2, kTopLevelsMax);
+    if (const char *e = getenv("TAHOE_LDS_LEVELS")) {  // tuning knob for experiments; never raises the caps
+        f->lds_levels = std::max(0, std::min(f->lds_levels, atoi(e)));
+        f->top_levels = std::max(0, std::min(f->top_levels, atoi(e)));
+    }
+    f->has_blocks = p->num_cols <= kBlockMaxCols;
 
+    // ---- normalise: heap records of the perfect depth-De tree ----
     const size_t T = (size_t)p->num_trees;
-    const size_t per_tree = (size_t)tahoe_tree_num_nodes(p->depth);
-    std::vector<InnerNode> h_inner(std::max<size_t>(T * f->n_inner, 1));
-    std::vector<float> h_leaf(std::max<size_t>(T * f->n_leaf, 1));
-    std::vector<uint32_t> h_orig(std::max<size_t>(T * f->n_leaf, 1));
-    std::vector<int64_t> inherit(per_tree);
+    const size_t src_nodes = (size_t)tahoe_tree_num_nodes(D);
+    const size_t all_nodes = f->n_inner + f->n_leaf;
+    std::vector<InnerNode> h_inner(T * f->n_inner);
+    std::vector<float> h_leaf(T * f->n_leaf);
+    std::vector<uint32_t> h_orig(T * f->n_leaf);
+    std::vector<int64_t> inherit(all_nodes);
     int max_fid = 0;
     for (size_t t = 0; t < T; ++t) {
-        const tahoe_dense_node *tree = nodes + t * per_tree;
-        for (size_t i = 0; i < per_tree; ++i) {
-            int fid, def_left, is_leaf;
-            float value;
-            tahoe_decode_node(&tree[i], &value, nullptr, &fid, &def_left, &is_leaf);
+        const tahoe_dense_node *tree = nodes + t * src_nodes;
+        for (size_t i = 0; i < all_nodes; ++i) {
             const int64_t up = i ? inherit[(i - 1) / 2] : -1;
-            if (up >= 0)
+            int fid = 0, def_left = 0, is_leaf = 0;
+            float value = 0.0f;
+            if (up >= 0) {
                 inherit[i] = up;  // below a leaf: unreachable in the original tree
-            else if (is_leaf)
-                inherit[i] = (int64_t)i;
-            else {
-                inherit[i] = -1;
-                if (i >= f->n_inner) {
-                    delete f;
-                    return fail(TAHOE_ERR_INVALID_FOREST,
-                                "tree %zu: reachable bottom-level node %zu is not a leaf (the reference would walk "
-                                "out of the tree)", t, i);
+            } else {
+                // i < src_nodes here: a node without a leaf above it is at most on the original bottom
+                // level, because the check below rejects non-leaves there.
+                tahoe_decode_node(&tree[i], &value, nullptr, &fid, &def_left, &is_leaf);
+                if (is_leaf) {
+                    inherit[i] = (int64_t)i;
+                } else {
+                    inherit[i] = -1;
+                    if (2 * i + 2 >= src_nodes) {
+                        delete f;
+                        return fail(TAHOE_ERR_INVALID_FOREST,
+                                    "tree %zu: reachable bottom-level node %zu is not a leaf (the reference would "
+                                    "walk out of the tree)", t, i);
+                    }
+                    if (fid >= p->num_cols) {
+                        delete f;
+                        return fail(TAHOE_ERR_INVALID_FOREST, "tree %zu node %zu: fid %d >= num_cols %d", t, i, fid,
+                                    p->num_cols);
+                    }
+                    max_fid = std::max(max_fid, fid);
                 }
-                if (fid >= p->num_cols) {
-                    delete f;
-                    return fail(TAHOE_ERR_INVALID_FOREST, "tree %zu node %zu: fid %d >= num_cols %d", t, i, fid,
-                                p->num_cols);
-                }
-                max_fid = std::max(max_fid, fid);
             }
             if (i < f->n_inner) {
                 InnerNode &n = h_inner[t * f->n_inner + i];
                 if (inherit[i] >= 0) {
-                    n.thr = 0.0f;
+                    n.thr = 0.0f;  // padding below a leaf: either child leads to the same value
                     n.meta = 0u;
                 } else {
                     n.thr = value;
@@ -423,33 +711,72 @@ tahoe_status tahoe_forest_create(tahoe_forest **out, const tahoe_dense_node *nod
     }
     f->bits_bytes = reference_bits_bytes(max_fid);
 
+    // ---- TILEBLOCK views: SoA tops and 32-byte bottom blocks ----
+    std::vector<unsigned char> h_top;
+    std::vector<uint4> h_blocks;
+    if (f->has_blocks) {
+        const int n_top = top_nodes(f->top_levels);
+        const int stride = top_stride_bytes(f->top_levels);
+        const int meta_off = top_thr_bytes(f->top_levels);
+        h_top.assign(T * (size_t)stride, 0);
+        const size_t n_blocks = (size_t)1 << (De - 2);
+        const size_t first = n_blocks - 1;
+        h_blocks.resize(T * n_blocks * 2);
+        for (size_t t = 0; t < T; ++t) {
+            const InnerNode *in = &h_inner[t * f->n_inner];
+            float *thr = reinterpret_cast<float *>(&h_top[t * stride]);
+            uint16_t *meta = reinterpret_cast<uint16_t *>(&h_top[t * stride + meta_off]);
+            for (int i = 0; i < n_top; ++i) {  // heap node i -> position i + 1
+                thr[i + 1] = in[i].thr;
+                meta[i + 1] = (uint16_t)((in[i].meta & 0x7fffu) | ((in[i].meta >> 31) << 15));
+            }
+            for (size_t b = 0; b < n_blocks; ++b) {
+                const size_t r = first + b, l = 2 * r + 1, rr = 2 * r + 2;  // subtree root and its children
+                auto pack = [](const InnerNode &n) { return (n.meta & 0x1ffu) | ((n.meta >> 31) << 9); };
+                uint4 a, v;
+                memcpy(&a.x, &in[r].thr, 4);
+                memcpy(&a.y, &in[l].thr, 4);
+                memcpy(&a.z, &in[rr].thr, 4);
+                a.w = pack(in[r]) | (pack(in[l]) << 10) | (pack(in[rr]) << 20);
+                const float *lv = &h_leaf[t * f->n_leaf + 4 * b];
+                memcpy(&v.x, &lv[0], 4);
+                memcpy(&v.y, &lv[1], 4);
+                memcpy(&v.z, &lv[2], 4);
+                memcpy(&v.w, &lv[3], 4);
+                h_blocks[(t * n_blocks + b) * 2 + 0] = a;
+                h_blocks[(t * n_blocks + b) * 2 + 1] = v;
+            }
+        }
+    }
+
     auto bail = [&](hipError_t e, const char *what) {
         tahoe_forest_destroy(f);
         return fail(TAHOE_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
     };
     hipError_t e;
-    const size_t inner_bytes = h_inner.size() * sizeof(InnerNode), leaf_bytes = h_leaf.size() * sizeof(float),
-                 orig_bytes = h_orig.size() * sizeof(uint32_t);
-    if ((e = hipMalloc(&f->inner, inner_bytes)) != hipSuccess) return bail(e, "hipMalloc(inner)");
-    if ((e = hipMalloc(&f->leaf_val, leaf_bytes)) != hipSuccess) return bail(e, "hipMalloc(leaf_val)");
-    if ((e = hipMalloc(&f->leaf_orig, orig_bytes)) != hipSuccess) return bail(e, "hipMalloc(leaf_orig)");
-    f->device_bytes = inner_bytes + leaf_bytes + orig_bytes;
-    if ((e = hipMemcpy(f->inner, h_inner.data(), inner_bytes, hipMemcpyHostToDevice)) != hipSuccess)
-        return bail(e, "hipMemcpy(inner)");
-    if ((e = hipMemcpy(f->leaf_val, h_leaf.data(), leaf_bytes, hipMemcpyHostToDevice)) != hipSuccess)
-        return bail(e, "hipMemcpy(leaf_val)");
-    if ((e = hipMemcpy(f->leaf_orig, h_orig.data(), orig_bytes, hipMemcpyHostToDevice)) != hipSuccess)
-        return bail(e, "hipMemcpy(leaf_orig)");
+    if ((e = upload(&f->inner, h_inner, &f->device_bytes)) != hipSuccess) return bail(e, "upload(inner)");
+    if ((e = upload(&f->leaf_val, h_leaf, &f->device_bytes)) != hipSuccess) return bail(e, "upload(leaf_val)");
+    if ((e = upload(&f->leaf_orig, h_orig, &f->device_bytes)) != hipSuccess) return bail(e, "upload(leaf_orig)");
+    if (f->has_blocks) {
+        if ((e = upload(&f->top, h_top, &f->device_bytes)) != hipSuccess) return bail(e, "upload(top)");
+        if ((e = upload(&f->blocks, h_blocks, &f->device_bytes)) != hipSuccess) return bail(e, "upload(blocks)");
+    }
 
     // Kernels that may need more than the default 64 KiB of dynamic LDS.
     if (rowtile_fits(f)) {
         const int lds = rowtile_lds_bytes(p->num_cols, f->lds_levels);
-        if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rowtile_kernel<false>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess)
-            return bail(e, "hipFuncSetAttribute(rowtile<false>)");
-        if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rowtile_kernel<true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess)
-            return bail(e, "hipFuncSetAttribute(rowtile<true>)");
+        if ((e = allow_lds(&rowtile_kernel<false>, lds)) != hipSuccess) return bail(e, "hipFuncSetAttribute(rowtile)");
+        if ((e = allow_lds(&rowtile_kernel<true>, lds)) != hipSuccess) return bail(e, "hipFuncSetAttribute(rowtile)");
+    }
+    if (f->has_blocks && tileblock_lds_bytes(f, 128) <= f->lds_limit) {
+        const long long lds = tileblock_lds_bytes(f, 128);
+        if ((e = allow_lds(&tileblock_kernel<128, false>, lds)) != hipSuccess) return bail(e, "hipFuncSetAttribute(tileblock)");
+        if ((e = allow_lds(&tileblock_kernel<128, true>, lds)) != hipSuccess) return bail(e, "hipFuncSetAttribute(tileblock)");
+    }
+    if (f->has_blocks && tileblock_lds_bytes(f, 64) <= f->lds_limit) {
+        const long long lds = tileblock_lds_bytes(f, 64);
+        if ((e = allow_lds(&tileblock_kernel<64, false>, lds)) != hipSuccess) return bail(e, "hipFuncSetAttribute(tileblock)");
+        if ((e = allow_lds(&tileblock_kernel<64, true>, lds)) != hipSuccess) return bail(e, "hipFuncSetAttribute(tileblock)");
     }
     *out = f;
     return TAHOE_OK;
@@ -461,6 +788,8 @@ void tahoe_forest_destroy(tahoe_forest *f)
     if (f->inner) (void)hipFree(f->inner);
     if (f->leaf_val) (void)hipFree(f->leaf_val);
     if (f->leaf_orig) (void)hipFree(f->leaf_orig);
+    if (f->top) (void)hipFree(f->top);
+    if (f->blocks) (void)hipFree(f->blocks);
     for (hipEvent_t e : f->ev_start) (void)hipEventDestroy(e);
     for (hipEvent_t e : f->ev_stop) (void)hipEventDestroy(e);
     delete f;
@@ -503,11 +832,14 @@ tahoe_status tahoe_transform_preds(float *preds_dev, size_t rows, int output, in
 tahoe_status tahoe_forest_set_strategy(tahoe_forest *f, int strategy)
 {
     if (!f) return fail(TAHOE_ERR_INVALID_ARG, "null forest");
-    if (strategy < TAHOE_STRATEGY_AUTO || strategy > TAHOE_STRATEGY_ROWTILE)
+    if (strategy < TAHOE_STRATEGY_AUTO || strategy > TAHOE_STRATEGY_TILEBLOCK)
         return fail(TAHOE_ERR_INVALID_ARG, "unknown strategy %d", strategy);
     if (strategy == TAHOE_STRATEGY_ROWTILE && !rowtile_fits(f))
         return fail(TAHOE_ERR_UNSUPPORTED, "ROWTILE needs %d B of LDS for %d columns; device offers %d",
                     rowtile_lds_bytes(f->p.num_cols, f->lds_levels), f->p.num_cols, f->lds_limit);
+    if (strategy == TAHOE_STRATEGY_TILEBLOCK && tileblock_rows(f) == 0)
+        return fail(TAHOE_ERR_UNSUPPORTED, "TILEBLOCK needs num_cols <= %d and a 64-row tile that fits %d B of LDS",
+                    kBlockMaxCols, f->lds_limit);
     f->strategy = strategy;
     return TAHOE_OK;
 }
@@ -519,7 +851,7 @@ tahoe_status tahoe_forest_get_info(const tahoe_forest *f, tahoe_forest_info *inf
     if (!f || !info) return fail(TAHOE_ERR_INVALID_ARG, "null argument");
     memset(info, 0, sizeof(*info));
     info->num_trees = f->p.num_trees;
-    info->depth = f->depth;
+    info->depth = f->p.depth;
     info->num_cols = f->p.num_cols;
     info->bits_bytes = f->bits_bytes;
     info->lds_levels = f->lds_levels;
@@ -527,6 +859,9 @@ tahoe_status tahoe_forest_get_info(const tahoe_forest *f, tahoe_forest_info *inf
     info->lds_bytes_per_block = rowtile_fits(f) ? rowtile_lds_bytes(f->p.num_cols, f->lds_levels) : 0;
     info->device_id = f->device;
     info->num_cus = f->num_cus;
+    info->top_levels = f->top_levels;
+    info->tile_rows = tileblock_rows(f);
+    info->tileblock_lds_bytes = info->tile_rows ? (int)tileblock_lds_bytes(f, info->tile_rows) : 0;
     return TAHOE_OK;
 }
 

@@ -32,9 +32,10 @@ def run_case(env, nodes, T, D, C, data, strategies=None, missing=MISSING, **out)
     want, want_leaf = oracle.predict(nodes, T, D, data, missing, want_leaf=True)
     x = torch.from_numpy(np.ascontiguousarray(data)).cuda()
     forest = ta.Forest(nodes, T, D, C, missing=missing)
-    lds_ok = forest.info().lds_bytes_per_block > 0
+    info = forest.info()
     if strategies is None:
-        strategies = [ta.STRATEGY_DIRECT] + ([ta.STRATEGY_ROWTILE] if lds_ok else []) + [ta.STRATEGY_AUTO]
+        strategies = [ta.STRATEGY_DIRECT] + ([ta.STRATEGY_ROWTILE] if info.lds_bytes_per_block > 0 else []) + (
+            [ta.STRATEGY_TILEBLOCK] if info.tile_rows > 0 else []) + [ta.STRATEGY_AUTO]
     for s in strategies:
         forest.set_strategy(s)
         leaf, sums = forest.predict_leaf_idx(x)
