@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--cols", type=int, default=256)
     ap.add_argument("--rows", type=int, default=1_000_000)
     ap.add_argument("--shard", choices=["rows", "trees"], default="rows")
-    ap.add_argument("--strategy", type=int, default=0, help="0 auto, 1 direct, 2 rowtile, 3 tileblock")
+    ap.add_argument("--strategy", type=int, default=0, help="0 auto, 1 direct, 2 rowtile, 3 tileblock, 4 tilering")
     ap.add_argument("--cpu-rows", type=int, default=100_000, help="rows of the batch timed on the CPU oracle")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
@@ -124,7 +124,7 @@ def main():
     k_ms = float(np.mean(kernel_ms)) if len(kernel_ms) else float("nan")
     achieved = b_alg / (k_ms * 1e-3) / 1e9
     roofline = {
-        "bound": "hbm", "kernel": {1: "direct_kernel", 2: "rowtile_kernel", 3: "tileblock_kernel"}.get(forest.get_strategy(R)),
+        "bound": "hbm", "kernel": ta.STRATEGY_NAMES.get(forest.get_strategy(R), "?") + "_kernel",
         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
         "kernel_ms_avg": round(k_ms, 4), "kernel_ms_min": round(float(np.min(kernel_ms)), 4) if len(kernel_ms) else None,
@@ -173,7 +173,7 @@ def main():
                                    + (" per GPU" if world > 1 and args.shard == "rows" else ""),
                        "trees": T, "depth": D, "cols": C, "rows_per_step": total_rows,
                        "sharding": "none" if world == 1 else args.shard,
-                       "strategy": {1: "direct", 2: "rowtile", 3: "tileblock"}.get(forest.get_strategy(R))},
+                       "strategy": ta.STRATEGY_NAMES.get(forest.get_strategy(R))},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

@@ -93,9 +93,12 @@ enum {
                                     levels of each tree staged in LDS, deeper levels gathered from
                                     global memory, ordered leaf-sum exchange; any num_cols whose
                                     tile fits LDS */
-    TAHOE_STRATEGY_TILEBLOCK = 3 /* num_cols <= 512: 128- (or 64-) row tile in LDS, four trees in
+    TAHOE_STRATEGY_TILEBLOCK = 3,/* num_cols <= 512: 128- (or 64-) row tile in LDS, four trees in
                                     flight, top 10 levels SoA in LDS, last two levels + leaves from
-                                    one 32-byte block per walk */
+                                    one 32-byte block per walk; two barriers per round of 4 trees */
+    TAHOE_STRATEGY_TILERING = 4  /* TILEBLOCK's data path with decoupled waves: walker waves with
+                                    private tops, no barrier in the tree loop, one consumer wave adds
+                                    leaf values in tree order through an LDS ring */
 };
 
 typedef struct tahoe_forest tahoe_forest; /* opaque */
@@ -131,6 +134,9 @@ tahoe_status tahoe_transform_preds(float *preds_dev, size_t rows, int output, in
                                    float threshold, float global_bias, void *stream);
 
 tahoe_status tahoe_forest_set_strategy(tahoe_forest *f, int strategy);
+/* Waits for `stream` and reports TAHOE_ERR_HIP if a kernel flagged an internal error (a bounded
+ * LDS wait of TILERING timing out); TAHOE_OK otherwise. */
+tahoe_status tahoe_forest_check(tahoe_forest *f, void *stream);
 /* Strategy the next predict will run (after AUTO resolution for `rows`). */
 int tahoe_forest_get_strategy(const tahoe_forest *f, size_t rows);
 
@@ -146,6 +152,8 @@ typedef struct {
     int top_levels;          /* top levels staged in LDS by TILEBLOCK */
     int tile_rows;           /* rows per TILEBLOCK tile: 128, 64, or 0 = strategy unavailable */
     int tileblock_lds_bytes; /* dynamic LDS of the TILEBLOCK kernel */
+    int ring_rows;           /* rows per TILERING tile: 64, 128, or 0 = strategy unavailable */
+    int tilering_lds_bytes;  /* dynamic LDS of the TILERING kernel */
 } tahoe_forest_info;
 tahoe_status tahoe_forest_get_info(const tahoe_forest *f, tahoe_forest_info *info);
 

@@ -23,4 +23,6 @@ from .capi import (  # noqa: F401
     STRATEGY_DIRECT,
     STRATEGY_ROWTILE,
     STRATEGY_TILEBLOCK,
+    STRATEGY_TILERING,
+    STRATEGY_NAMES,
 )

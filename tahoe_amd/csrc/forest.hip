@@ -85,6 +85,7 @@ struct tahoe_forest {
     uint32_t *leaf_orig = nullptr;
     unsigned char *top = nullptr;  // [T][top_stride]
     uint4 *blocks = nullptr;       // [T][2^(De-2)][2]
+    int *error_flag = nullptr;     // set by TILERING if a bounded spin ever times out
     size_t device_bytes = 0;
     // Profiling: one hipEvent pair per traversal launch, read back after the stream has drained.
     bool profiling = false;
@@ -438,6 +439,258 @@ __global__ void __launch_bounds__(kSlots *ROWS)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// TILERING: TILEBLOCK's data path with the waves decoupled.  No workgroup barrier inside the tree loop.
+//   * NWALK walker waves, each with a private LDS slot for the top of its current tree; walker w walks
+//     trees w, w+NWALK, ... for all ROWS rows of the tile (K = ROWS/64 interleaved chains per lane), and
+//     prefetches the next top into registers meanwhile.  Waves drift freely, so one wave's global
+//     gather latency is covered by the others' LDS walks.
+//   * One consumer wave adds the leaf values in tree order (bit-exact float32 sums).  Walkers hand
+//     them over through a ring in LDS: vals[RING][ROWS] + ready[RING] (holds tree+1) + one `consumed`
+//     counter; single-CU LDS traffic is processed in order, so a flag written after its data is seen
+//     after its data.  Every spin is bounded: on timeout the kernel sets *error_flag and drains.
+// Dynamic LDS: [cols][ROWS] float | NWALK x top_stride | [RING][ROWS] float | ready[RING] | consumed.
+constexpr int kRingSpinLimit = 1 << 22;
+
+template <int ROWS>
+struct RingGeom {
+    static constexpr int RING = (ROWS == 64) ? 32 : 8;   // ring entries (trees)
+    static constexpr int BATCH = (ROWS == 64) ? 8 : 4;   // trees the consumer takes per poll
+};
+
+template <int ROWS, int NWALK, bool WRITE_LEAF>
+__global__ void __launch_bounds__((NWALK + 1) * 64)
+    tilering_kernel(const unsigned char *__restrict__ top, const uint4 *__restrict__ blocks,
+                    const InnerNode *__restrict__ inner, const uint32_t *__restrict__ leaf_orig,
+                    const float *__restrict__ data, float *__restrict__ sums, uint32_t *__restrict__ leaf_out,
+                    size_t rows, int cols, int num_trees, int depth, int top_levels, int top_stride, float missing,
+                    int vec4_ok, int *__restrict__ error_flag)
+{
+    constexpr int K = ROWS / 64;
+    constexpr int NT = (NWALK + 1) * 64;
+    constexpr int RING = RingGeom<ROWS>::RING;
+    constexpr int BATCH = RingGeom<ROWS>::BATCH;
+    static_assert(BATCH <= RING && BATCH <= 64, "consumer batch must fit the ring");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    float *tile = reinterpret_cast<float *>(smem);
+    unsigned char *slots = smem + (size_t)cols * ROWS * sizeof(float);
+    volatile float *ring_vals = reinterpret_cast<volatile float *>(slots + (size_t)NWALK * top_stride);
+    volatile uint32_t *ring_ready = reinterpret_cast<volatile uint32_t *>(
+        slots + (size_t)NWALK * top_stride + (size_t)RING * ROWS * sizeof(float));
+    volatile uint32_t *consumed = ring_ready + RING;
+
+    const size_t row0 = (size_t)blockIdx.x * ROWS;
+
+    // ---- stage the row tile, transposed to feature-major; reset the ring ----
+    if (vec4_ok) {
+        const int n4 = cols / 4;
+        for (int e = tid; e < ROWS * n4; e += NT) {
+            const int trow = e % ROWS, f4 = e / ROWS;
+            const size_t grow = row0 + trow;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (grow < rows) v = reinterpret_cast<const float4 *>(data + grow * (size_t)cols)[f4];
+            tile[(4 * f4 + 0) * ROWS + trow] = v.x;
+            tile[(4 * f4 + 1) * ROWS + trow] = v.y;
+            tile[(4 * f4 + 2) * ROWS + trow] = v.z;
+            tile[(4 * f4 + 3) * ROWS + trow] = v.w;
+        }
+    } else {
+        for (int e = tid; e < ROWS * cols; e += NT) {
+            const int trow = e % ROWS, f = e / ROWS;
+            const size_t grow = row0 + trow;
+            tile[f * ROWS + trow] = grow < rows ? data[grow * (size_t)cols + f] : 0.0f;
+        }
+    }
+    if (tid < RING) ring_ready[tid] = 0u;
+    if (tid == RING) *consumed = 0u;
+
+    if (wave == NWALK) {
+        // ================= consumer: ordered accumulation =================
+        __syncthreads();
+        float sum[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) sum[k] = 0.0f;
+        bool dead = false;
+        for (int t0 = 0; t0 < num_trees && !dead; t0 += BATCH) {
+            const int nb = min(BATCH, num_trees - t0);
+            int spins = 0;
+            for (;;) {
+                const bool ok = lane >= nb || ring_ready[(t0 + lane) % RING] == (uint32_t)(t0 + lane + 1);
+                if (__ballot(ok) == ~0ull) break;
+                if (++spins > kRingSpinLimit) {
+                    dead = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (dead) break;
+            for (int j = 0; j < nb; ++j) {
+                const int e = (t0 + j) % RING;
+#pragma unroll
+                for (int k = 0; k < K; ++k) sum[k] += ring_vals[e * ROWS + k * 64 + lane];  // tree order
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) *consumed = (uint32_t)(t0 + nb);
+        }
+        if (dead && lane == 0) atomicOr(error_flag, 1);
+        if (sums) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const size_t orow = row0 + k * 64 + lane;
+                if (orow < rows) sums[orow] = sum[k];
+            }
+        }
+        return;
+    }
+
+    // ================= walkers =================
+    unsigned char *slot = slots + (size_t)wave * top_stride;
+    const float *s_thr = reinterpret_cast<const float *>(slot);
+    const uint16_t *s_meta = reinterpret_cast<const uint16_t *>(slot + (((4 << top_levels) + 15) & ~15));
+    const int n_chunks = top_stride >> 4;
+
+    // Next tree's top: six 16-byte chunks per lane (6 KiB per slot), named registers (an indexed array
+    // would live in scratch memory).
+    uint4 pf0 = {}, pf1 = {}, pf2 = {}, pf3 = {}, pf4 = {}, pf5 = {};
+    auto prefetch_top = [&](int t) {
+        const uint4 *g = reinterpret_cast<const uint4 *>(top + (size_t)t * top_stride);
+        const int last = n_chunks - 1;  // clamped: branch-free and in bounds
+        pf0 = g[min(0 * 64 + lane, last)];
+        pf1 = g[min(1 * 64 + lane, last)];
+        pf2 = g[min(2 * 64 + lane, last)];
+        pf3 = g[min(3 * 64 + lane, last)];
+        pf4 = g[min(4 * 64 + lane, last)];
+        pf5 = g[min(5 * 64 + lane, last)];
+    };
+    auto commit_top = [&]() {
+        uint4 *s = reinterpret_cast<uint4 *>(slot);
+        if (0 * 64 + lane < n_chunks) s[0 * 64 + lane] = pf0;
+        if (1 * 64 + lane < n_chunks) s[1 * 64 + lane] = pf1;
+        if (2 * 64 + lane < n_chunks) s[2 * 64 + lane] = pf2;
+        if (3 * 64 + lane < n_chunks) s[3 * 64 + lane] = pf3;
+        if (4 * 64 + lane < n_chunks) s[4 * 64 + lane] = pf4;
+        if (5 * 64 + lane < n_chunks) s[5 * 64 + lane] = pf5;
+    };
+    if (wave < num_trees) {
+        prefetch_top(wave);
+        commit_top();
+    }
+    __syncthreads();  // the tile, the ring state and (own wave) the first top are in LDS
+
+    const size_t n_inner = ((size_t)1 << depth) - 1;
+    const uint32_t n_blocks = 1u << (depth - 2);
+    const uint32_t first_block_node = n_blocks - 1;
+    bool dead = false;
+    for (int t = wave; t < num_trees && !dead; t += NWALK) {
+        const bool more = t + NWALK < num_trees;
+        if (more) prefetch_top(t + NWALK);
+        // K interleaved chains: chain k walks row k*64 + lane.  1-based heap positions; the children
+        // of position i are the aligned pair (2i, 2i+1), read together with the node's feature.
+        uint32_t i[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) i[k] = 1;
+        if (top_levels > 0) {
+            float thr[K];
+            uint32_t m[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                thr[k] = s_thr[1];
+                m[k] = s_meta[1];
+            }
+            for (int l = 0; l < top_levels - 1; ++l) {
+                float x[K];
+                float2 t2[K];
+                uint32_t m2[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    x[k] = tile[(m[k] & 0x7fffu) * ROWS + k * 64 + lane];
+                    t2[k] = *reinterpret_cast<const float2 *>(&s_thr[2 * i[k]]);
+                    m2[k] = *reinterpret_cast<const uint32_t *>(&s_meta[2 * i[k]]);
+                }
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const uint32_t c = go_right(x[k], thr[k], (m[k] >> 15) != 0, missing);
+                    i[k] = 2u * i[k] + c;
+                    thr[k] = c ? t2[k].y : t2[k].x;
+                    m[k] = c ? (m2[k] >> 16) : (m2[k] & 0xffffu);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float x = tile[(m[k] & 0x7fffu) * ROWS + k * 64 + lane];
+                i[k] = 2u * i[k] + go_right(x, thr[k], (m[k] >> 15) != 0, missing);
+            }
+        }
+        float v[K];
+        uint32_t bsel[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            uint32_t idx = i[k] - 1;  // 0-based heap index on level top_levels
+            if (top_levels < depth - 2) {  // deep trees only (De > 12): heap records from global memory
+                const InnerNode *tree = inner + (size_t)t * n_inner;
+                for (int l = top_levels; l < depth - 2; ++l) {
+                    const InnerNode n = tree[idx];
+                    const float x = tile[(n.meta & 0x7fffffffu) * ROWS + k * 64 + lane];
+                    idx = step(idx, n.thr, n.meta, x, missing);
+                }
+            }
+            bsel[k] = idx - first_block_node;
+        }
+        uint4 na[K], nb[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint4 *bp = blocks + ((size_t)t * n_blocks + bsel[k]) * 2;
+            na[k] = bp[0];  // thr0, thr1, thr2, packed metas
+            nb[k] = bp[1];  // four leaf values
+            // whole 16-byte loads, issued here (the compiler otherwise sinks single dwords into branches)
+            asm volatile("" ::"v"(na[k].x), "v"(na[k].y), "v"(na[k].z), "v"(na[k].w));
+            asm volatile("" ::"v"(nb[k].x), "v"(nb[k].y), "v"(nb[k].z), "v"(nb[k].w));
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint32_t m = na[k].w;
+            const float x0 = tile[(m & 0x1ffu) * ROWS + k * 64 + lane];
+            const float x1 = tile[((m >> 10) & 0x1ffu) * ROWS + k * 64 + lane];
+            const float x2 = tile[((m >> 20) & 0x1ffu) * ROWS + k * 64 + lane];
+            const uint32_t c0 = go_right(x0, __uint_as_float(na[k].x), ((m >> 9) & 1u) != 0, missing);
+            const uint32_t c1l = go_right(x1, __uint_as_float(na[k].y), ((m >> 19) & 1u) != 0, missing);
+            const uint32_t c1r = go_right(x2, __uint_as_float(na[k].z), ((m >> 29) & 1u) != 0, missing);
+            const uint32_t c1 = c0 ? c1r : c1l;
+            const uint32_t lo = c1 ? nb[k].y : nb[k].x, hi = c1 ? nb[k].w : nb[k].z;
+            v[k] = __uint_as_float(c0 ? hi : lo);
+            if (WRITE_LEAF) {
+                const size_t row = row0 + k * 64 + lane;
+                if (row < rows)
+                    leaf_out[row * (size_t)num_trees + t] =
+                        leaf_orig[(size_t)t * ((size_t)n_blocks * 4) + (size_t)bsel[k] * 4 + 2 * c0 + c1];
+            }
+        }
+        // ---- hand the leaf values to the consumer ----
+        if (t >= RING) {
+            int spins = 0;
+            while (*consumed < (uint32_t)(t - RING + 1)) {
+                if (++spins > kRingSpinLimit) {
+                    dead = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        const int e = t % RING;
+#pragma unroll
+        for (int k = 0; k < K; ++k) ring_vals[e * ROWS + k * 64 + lane] = v[k];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) ring_ready[e] = (uint32_t)(t + 1);
+        if (more) commit_top();  // this wave's reads of its slot are done (in-order LDS)
+    }
+    if (dead && lane == 0) atomicOr(error_flag, 1);
+}
+
 // transform_k (Struct.h:196-209) with the CPU predictor's arithmetic (BaseTahoeTest.h:467-472):
 // AVG divides by num_trees (the reference's GPU epilogue multiplies by 1/T instead).
 __global__ void transform_kernel(float *preds, size_t n, int output, int num_trees, float threshold,
@@ -486,9 +739,30 @@ static int tileblock_rows(const tahoe_forest *f)
     return 0;
 }
 
+static long long tilering_lds_bytes(const tahoe_forest *f, int tile_rows)
+{
+    const int nwalk = tile_rows == 64 ? 8 : 4;
+    const int ring = tile_rows == 64 ? RingGeom<64>::RING : RingGeom<128>::RING;
+    return (long long)f->p.num_cols * tile_rows * 4 + (long long)nwalk * top_stride_bytes(f->top_levels) +
+           (long long)ring * tile_rows * 4 + (ring + 1) * 4LL;
+}
+
+// Rows per TILERING tile: 64 (8 walkers x 1 chain) or 128 (4 walkers x 2 chains); 0 = unavailable.
+static int tilering_rows(const tahoe_forest *f)
+{
+    if (!f->has_blocks || f->p.num_cols < 1) return 0;
+    if (const char *e = getenv("TAHOE_TILE_ROWS")) {  // tuning knob for experiments
+        const int r = atoi(e);
+        if ((r == 64 || r == 128) && tilering_lds_bytes(f, r) <= f->lds_limit) return r;
+    }
+    if (tilering_lds_bytes(f, 64) <= f->lds_limit) return 64;
+    return 0;
+}
+
 static int resolve_strategy(const tahoe_forest *f, size_t /*rows*/)
 {
     if (f->strategy != TAHOE_STRATEGY_AUTO) return f->strategy;
+    if (tilering_rows(f) > 0) return TAHOE_STRATEGY_TILERING;
     if (tileblock_rows(f) > 0) return TAHOE_STRATEGY_TILEBLOCK;
     return rowtile_fits(f) ? TAHOE_STRATEGY_ROWTILE : TAHOE_STRATEGY_DIRECT;
 }
@@ -510,6 +784,23 @@ static void launch_tileblock(tahoe_forest *f, float *sums, uint32_t *leaf_out, c
                            f->p.num_trees, f->depth, f->top_levels, stride, f->p.missing, vec4_ok);
 }
 
+template <int ROWS, int NWALK>
+static void launch_tilering(tahoe_forest *f, float *sums, uint32_t *leaf_out, const float *data, size_t rows,
+                            hipStream_t stream, int vec4_ok)
+{
+    const unsigned grid = (unsigned)((rows + ROWS - 1) / ROWS);
+    const int lds = (int)tilering_lds_bytes(f, ROWS);
+    const int stride = top_stride_bytes(f->top_levels);
+    if (leaf_out)
+        hipLaunchKernelGGL((tilering_kernel<ROWS, NWALK, true>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream,
+                           f->top, f->blocks, f->inner, f->leaf_orig, data, sums, leaf_out, rows, f->p.num_cols,
+                           f->p.num_trees, f->depth, f->top_levels, stride, f->p.missing, vec4_ok, f->error_flag);
+    else
+        hipLaunchKernelGGL((tilering_kernel<ROWS, NWALK, false>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream,
+                           f->top, f->blocks, f->inner, f->leaf_orig, data, sums, leaf_out, rows, f->p.num_cols,
+                           f->p.num_trees, f->depth, f->top_levels, stride, f->p.missing, vec4_ok, f->error_flag);
+}
+
 static tahoe_status launch_traversal(tahoe_forest *f, float *sums, uint32_t *leaf_out, const float *data,
                                      size_t rows, hipStream_t stream)
 {
@@ -522,6 +813,16 @@ static tahoe_status launch_traversal(tahoe_forest *f, float *sums, uint32_t *lea
     if (f->p.num_trees == 0) {
         // Nothing to walk: sums are zero (an empty j-loop in predict_on_cpu).
         if (sums) TAHOE_HIP_TRY(hipMemsetAsync(sums, 0, rows * sizeof(float), stream));
+    } else if (strategy == TAHOE_STRATEGY_TILERING) {
+        const int tr = tilering_rows(f);
+        if (tr == 0)
+            return fail(TAHOE_ERR_UNSUPPORTED, "TILERING needs num_cols <= %d and a 64-row tile that fits %d B of LDS",
+                        kBlockMaxCols, f->lds_limit);
+        if (tr == 128)
+            launch_tilering<128, 4>(f, sums, leaf_out, data, rows, stream, vec4_ok);
+        else
+            launch_tilering<64, 8>(f, sums, leaf_out, data, rows, stream, vec4_ok);
+        TAHOE_HIP_TRY(hipGetLastError());
     } else if (strategy == TAHOE_STRATEGY_TILEBLOCK) {
         const int tr = tileblock_rows(f);
         if (tr == 0)
@@ -773,6 +1074,21 @@ tahoe_status tahoe_forest_create(tahoe_forest **out, const tahoe_dense_node *nod
         if ((e = allow_lds(&tileblock_kernel<128, false>, lds)) != hipSuccess) return bail(e, "hipFuncSetAttribute(tileblock)");
         if ((e = allow_lds(&tileblock_kernel<128, true>, lds)) != hipSuccess) return bail(e, "hipFuncSetAttribute(tileblock)");
     }
+    if (f->has_blocks) {
+        if ((e = hipMalloc(reinterpret_cast<void **>(&f->error_flag), sizeof(int))) != hipSuccess)
+            return bail(e, "hipMalloc(error_flag)");
+        if ((e = hipMemset(f->error_flag, 0, sizeof(int))) != hipSuccess) return bail(e, "hipMemset(error_flag)");
+    }
+    if (f->has_blocks && tilering_lds_bytes(f, 64) <= f->lds_limit) {
+        const long long lds = tilering_lds_bytes(f, 64);
+        if ((e = allow_lds(&tilering_kernel<64, 8, false>, lds)) != hipSuccess) return bail(e, "hipFuncSetAttribute(tilering)");
+        if ((e = allow_lds(&tilering_kernel<64, 8, true>, lds)) != hipSuccess) return bail(e, "hipFuncSetAttribute(tilering)");
+    }
+    if (f->has_blocks && tilering_lds_bytes(f, 128) <= f->lds_limit) {
+        const long long lds = tilering_lds_bytes(f, 128);
+        if ((e = allow_lds(&tilering_kernel<128, 4, false>, lds)) != hipSuccess) return bail(e, "hipFuncSetAttribute(tilering)");
+        if ((e = allow_lds(&tilering_kernel<128, 4, true>, lds)) != hipSuccess) return bail(e, "hipFuncSetAttribute(tilering)");
+    }
     if (f->has_blocks && tileblock_lds_bytes(f, 64) <= f->lds_limit) {
         const long long lds = tileblock_lds_bytes(f, 64);
         if ((e = allow_lds(&tileblock_kernel<64, false>, lds)) != hipSuccess) return bail(e, "hipFuncSetAttribute(tileblock)");
@@ -790,6 +1106,7 @@ void tahoe_forest_destroy(tahoe_forest *f)
     if (f->leaf_orig) (void)hipFree(f->leaf_orig);
     if (f->top) (void)hipFree(f->top);
     if (f->blocks) (void)hipFree(f->blocks);
+    if (f->error_flag) (void)hipFree(f->error_flag);
     for (hipEvent_t e : f->ev_start) (void)hipEventDestroy(e);
     for (hipEvent_t e : f->ev_stop) (void)hipEventDestroy(e);
     delete f;
@@ -832,7 +1149,7 @@ tahoe_status tahoe_transform_preds(float *preds_dev, size_t rows, int output, in
 tahoe_status tahoe_forest_set_strategy(tahoe_forest *f, int strategy)
 {
     if (!f) return fail(TAHOE_ERR_INVALID_ARG, "null forest");
-    if (strategy < TAHOE_STRATEGY_AUTO || strategy > TAHOE_STRATEGY_TILEBLOCK)
+    if (strategy < TAHOE_STRATEGY_AUTO || strategy > TAHOE_STRATEGY_TILERING)
         return fail(TAHOE_ERR_INVALID_ARG, "unknown strategy %d", strategy);
     if (strategy == TAHOE_STRATEGY_ROWTILE && !rowtile_fits(f))
         return fail(TAHOE_ERR_UNSUPPORTED, "ROWTILE needs %d B of LDS for %d columns; device offers %d",
@@ -840,7 +1157,22 @@ tahoe_status tahoe_forest_set_strategy(tahoe_forest *f, int strategy)
     if (strategy == TAHOE_STRATEGY_TILEBLOCK && tileblock_rows(f) == 0)
         return fail(TAHOE_ERR_UNSUPPORTED, "TILEBLOCK needs num_cols <= %d and a 64-row tile that fits %d B of LDS",
                     kBlockMaxCols, f->lds_limit);
+    if (strategy == TAHOE_STRATEGY_TILERING && tilering_rows(f) == 0)
+        return fail(TAHOE_ERR_UNSUPPORTED, "TILERING needs num_cols <= %d and a 64-row tile that fits %d B of LDS",
+                    kBlockMaxCols, f->lds_limit);
     f->strategy = strategy;
+    return TAHOE_OK;
+}
+
+tahoe_status tahoe_forest_check(tahoe_forest *f, void *stream)
+{
+    if (!f) return fail(TAHOE_ERR_INVALID_ARG, "null forest");
+    TAHOE_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    if (f->error_flag) {
+        int flag = 0;
+        TAHOE_HIP_TRY(hipMemcpy(&flag, f->error_flag, sizeof(int), hipMemcpyDeviceToHost));
+        if (flag != 0) return fail(TAHOE_ERR_HIP, "TILERING: a bounded LDS ring wait timed out; results are invalid");
+    }
     return TAHOE_OK;
 }
 
@@ -862,6 +1194,8 @@ tahoe_status tahoe_forest_get_info(const tahoe_forest *f, tahoe_forest_info *inf
     info->top_levels = f->top_levels;
     info->tile_rows = tileblock_rows(f);
     info->tileblock_lds_bytes = info->tile_rows ? (int)tileblock_lds_bytes(f, info->tile_rows) : 0;
+    info->ring_rows = tilering_rows(f);
+    info->tilering_lds_bytes = info->ring_rows ? (int)tilering_lds_bytes(f, info->ring_rows) : 0;
     return TAHOE_OK;
 }
 

@@ -35,12 +35,13 @@ def run_case(env, nodes, T, D, C, data, strategies=None, missing=MISSING, **out)
     info = forest.info()
     if strategies is None:
         strategies = [ta.STRATEGY_DIRECT] + ([ta.STRATEGY_ROWTILE] if info.lds_bytes_per_block > 0 else []) + (
-            [ta.STRATEGY_TILEBLOCK] if info.tile_rows > 0 else []) + [ta.STRATEGY_AUTO]
+            [ta.STRATEGY_TILEBLOCK] if info.tile_rows > 0 else []) + (
+            [ta.STRATEGY_TILERING] if info.ring_rows > 0 else []) + [ta.STRATEGY_AUTO]
     for s in strategies:
         forest.set_strategy(s)
         leaf, sums = forest.predict_leaf_idx(x)
         raw = forest.predict_raw(x)
-        torch.cuda.synchronize()
+        forest.check()
         assert np.array_equal(bits(leaf.cpu().numpy()), want_leaf), f"leaf index mismatch, strategy {s}"
         assert np.array_equal(bits(sums.cpu().numpy()), bits(want)), f"sum (leaf pass) mismatch, strategy {s}"
         assert np.array_equal(bits(raw.cpu().numpy()), bits(want)), f"sum mismatch, strategy {s}"
