@@ -87,6 +87,7 @@ def main():
 
     def step():
         if world > 1 and args.shard == "trees":
+            # tahoe_amd/sharding.py, TreeShardedForest.predict: partial sums, one all-reduce, transform
             forest.predict_raw(x, preds, stream=stream)
             dist.all_reduce(preds)  # RCCL over xGMI: 4 B/row
             ta.capi.transform_preds(preds, 0, T, 0.0, 0.0, stream=stream)

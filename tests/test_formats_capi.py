@@ -1,0 +1,161 @@
+"""Host-side pieces of the product library, CPU only: the C ABI loads and exports every symbol the header
+declares, the text-format loaders agree bit for bit with the oracle's restatement of the reference loaders
+(BaseTahoeTest.h:267-402), the writers round-trip, and compute entry points fail loudly without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ta(built):
+    import tahoe_amd
+
+    return tahoe_amd
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "tahoe_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tahoe_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(ta):
+    lib = ctypes.CDLL(ta.capi.LIB_PATH)
+    syms = header_symbols()
+    assert len(syms) >= 35
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, f"declared in include/tahoe_amd.h but not exported: {missing}"
+    # and the ctypes binding covers the header exactly
+    assert sorted(ta.capi.EXPORTED_SYMBOLS) == syms
+    assert ta.lib.tahoe_abi_version() == 1
+
+
+def test_node_encoding_matches_reference_masks(ta):
+    # encode_node / dense_node_decode, Struct.h:103-117
+    n = np.zeros(1, dtype=ta.NODE_DTYPE)
+    ta.lib.tahoe_encode_node(n.ctypes.data, 12345, 0.5, 1, 0.25, 1)
+    assert n["bits"][0] == np.int32(np.uint32(12345 | (1 << 30) | (1 << 31)))
+    assert n["val"][0] == np.float32(0.5) and n["weight"][0] == np.float32(0.25)
+    ta.lib.tahoe_encode_node(n.ctypes.data, (1 << 30) + 7, 1.0, 0, 0.0, 0)  # fid is masked to 30 bits
+    assert n["bits"][0] == 7
+    o = np.zeros(1, dtype=oracle.NODE_DTYPE)
+    oracle.lib.oracle_encode_node(o.ctypes.data, (1 << 30) + 7, 1.0, 0, 0.0, 0)
+    assert o.tobytes() == n.tobytes()
+    assert ta.capi.tree_num_nodes(12) == 8191 == oracle.tree_num_nodes(12)
+
+
+def both_loaders_agree(ta, model, data):
+    n1, t1, d1 = ta.load_model(model)
+    n2, t2, d2 = oracle.load_model(model)
+    assert (t1, d1) == (t2, d2) and n1.tobytes() == n2.tobytes()
+    x1, m1 = ta.load_data(data)
+    x2, m2 = oracle.load_data(data)
+    assert x1.shape == x2.shape and x1.tobytes() == x2.tobytes()
+    assert np.float32(m1).tobytes() == np.float32(m2).tobytes()
+    return n1, t1, d1, x1, m1
+
+
+def test_loaders_on_golden_files(ta):
+    import glob
+
+    for model in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "*.model.txt"))):
+        stem = model[: -len(".model.txt")]
+        nodes, T, D, data, missing = both_loaders_agree(ta, model, stem + ".data.txt")
+        exp = np.load(stem + ".expected.npz")
+        assert np.array_equal(nodes.view(np.uint32).reshape(-1, 3), exp["nodes_bits"])
+        assert np.array_equal(data.view(np.uint32), exp["data_bits"])
+
+
+def test_writer_round_trip_is_bit_exact(ta, tmp_path):
+    T, D, C, R = 7, 4, 11, 33
+    nodes = ta.synth_forest(T, D, C, seed=9, leaf_prob=0.2)
+    data = ta.synth_data(R, C, seed=10, missing_prob=0.1, missing=-999.0, nan_prob=0.1)
+    data[0, 0], data[0, 1], data[0, 2] = np.float32(1e-45), np.float32(3.4028235e38), -0.0  # denormal, max, -0
+    m, d = str(tmp_path / "m.txt"), str(tmp_path / "d.txt")
+    ta.write_model(m, nodes, T, D)
+    ta.write_data(d, data, -999.0)
+    n2, T2, D2, x2, miss = both_loaders_agree(ta, m, d)
+    assert (T2, D2) == (T, D) and n2.tobytes() == nodes.tobytes()
+    assert x2.tobytes() == data.tobytes() and miss == -999.0
+
+
+def test_loader_edge_cases_follow_the_reference(ta, tmp_path):
+    # (1) a file that ends early repeats its last line (unchecked fgets, BaseTahoeTest.h:298-307, :384)
+    m = tmp_path / "short_model.txt"
+    m.write_text("1\n2\n3\n0.5\n1\n0.25\n0\n7\n")  # root complete, node 1 starts with fid=7 and then EOF
+    d = tmp_path / "short_data.txt"
+    d.write_text("2\n3\n-999\n0.5\n1.5\n")  # 2x3 values wanted, 2 present
+    nodes, T, D, data, missing = both_loaders_agree(ta, str(m), str(d))
+    assert (T, D) == (1, 1) and nodes.size == 3
+    fid1 = int(nodes["bits"][1]) & ((1 << 30) - 1)
+    assert fid1 == 7 and nodes["val"][1] == np.float32(7.0) and (int(nodes["bits"][1]) & 0xFFFFFFFF) >> 31 == 1
+    assert data.tolist() == [[0.5, 1.5, 1.5], [1.5, 1.5, 1.5]]
+    # (2) atoi/atof semantics: leading spaces, trailing junk, exponents, CRLF
+    m2 = tmp_path / "junk_model.txt"
+    m2.write_text("1 trees\r\n1 levels\r\n  3xyz\r\n1e-1\r\n 2 \r\n0.5f\r\n1\r\n")
+    d2 = tmp_path / "junk_data.txt"
+    d2.write_text(" 1\r\n2 cols\r\nnan\r\n0x10\r\n-inf\r\n")
+    nodes, T, D, data, missing = both_loaders_agree(ta, str(m2), str(d2))
+    assert (T, D) == (1, 0) and (int(nodes["bits"][0]) & ((1 << 30) - 1)) == 3
+    assert nodes["val"][0] == np.float32(0.1) and np.isnan(missing)
+    assert data[0, 0] == 16.0 and data[0, 1] == -np.inf  # strtod parses hex floats, as atof does
+    # (3) unreadable file -> TAHOE_ERR_IO (the reference perror()s and exit(1)s)
+    with pytest.raises(ta.TahoeError) as e:
+        ta.load_model(str(tmp_path / "nope.txt"))
+    assert e.value.status == 2 and "fail to read" in str(e.value)
+    # (4) a missing header line keeps the caller's default (the reference keeps its ctor defaults)
+    empty = tmp_path / "empty.txt"
+    empty.write_text("")
+    x, miss = ta.load_data(str(empty), num_rows=2, num_cols=1, missing=0.5)
+    assert x.shape == (2, 1) and miss == 0.5
+    x2, miss2 = oracle.load_data(str(empty), num_rows=2, num_cols=1, missing=0.5)
+    assert x2.shape == (2, 1) and miss2 == 0.5
+
+
+def test_synthetic_generators_are_deterministic_and_shardable(ta):
+    a = ta.synth_data(100, 7, seed=5, missing_prob=0.1, missing=-1.0, nan_prob=0.1)
+    b = np.concatenate([ta.synth_data(40, 7, seed=5, missing_prob=0.1, missing=-1.0, nan_prob=0.1),
+                        ta.synth_data(60, 7, seed=5, missing_prob=0.1, missing=-1.0, nan_prob=0.1, first_row=40)])
+    assert a.tobytes() == b.tobytes()
+    assert (a == -1.0).any() and np.isnan(a).any()
+    clean = ta.synth_data(50, 3, seed=6)
+    assert clean.min() >= -1.0 and clean.max() < 1.0
+    f = ta.synth_forest(3, 4, 9, seed=1, leaf_prob=0.3)
+    assert f.tobytes() == ta.synth_forest(3, 4, 9, seed=1, leaf_prob=0.3).tobytes()
+    bits = f["bits"].view(np.uint32).reshape(3, 31)
+    assert ((bits[:, 15:] >> 31) == 1).all(), "bottom level must be leaves"
+    assert ((bits & ((1 << 30) - 1)) < 9).all()
+
+
+def test_no_gpu_means_loud_failure(ta):
+    """The product has no CPU path: without a device, create() must fail (never silently compute)."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(ta.TahoeError) as e:
+        ta.Forest(ta.synth_forest(2, 2, 3, seed=1), 2, 2, 3)
+    assert e.value.status == 4  # TAHOE_ERR_NO_DEVICE
+    n = ctypes.c_int(-1)
+    assert ta.lib.tahoe_device_count(ctypes.byref(n)) == 0 and n.value == 0
+    p = ctypes.c_void_p()
+    assert ta.lib.tahoe_device_alloc(ctypes.byref(p), 16, 1) == 4
+
+
+def test_product_never_touches_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use oracle/."""
+    pkg = os.path.join(ROOT, "tahoe_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hip", ".h", ".hpp", "Makefile")):
+                text = open(os.path.join(dirpath, fn), errors="replace").read()
+                assert "oracle" not in text.lower(), f"{os.path.join(dirpath, fn)} mentions the oracle"
+    syms = os.popen(f"nm -D --undefined-only {os.path.join(pkg, 'libtahoe_amd.so')} 2>/dev/null").read()
+    assert "oracle_" not in syms
