@@ -96,9 +96,13 @@ enum {
     TAHOE_STRATEGY_TILEBLOCK = 3,/* num_cols <= 512: 128- (or 64-) row tile in LDS, four trees in
                                     flight, top 10 levels SoA in LDS, last two levels + leaves from
                                     one 32-byte block per walk; two barriers per round of 4 trees */
-    TAHOE_STRATEGY_TILERING = 4  /* TILEBLOCK's data path with decoupled waves: walker waves with
+    TAHOE_STRATEGY_TILERING = 4, /* TILEBLOCK's data path with decoupled waves: walker waves with
                                     private tops, no barrier in the tree loop, one consumer wave adds
                                     leaf values in tree order through an LDS ring */
+    TAHOE_STRATEGY_QRING = 5     /* TILERING on rank-quantised data: features and thresholds become
+                                    exact 16-bit ranks (a per-predict quantise pass), 128-row u16 tile,
+                                    4-byte nodes, up to 15 walker waves x 2 chains; available when every
+                                    feature has <= 32767 distinct thresholds */
 };
 
 typedef struct tahoe_forest tahoe_forest; /* opaque */
@@ -137,6 +141,10 @@ tahoe_status tahoe_forest_set_strategy(tahoe_forest *f, int strategy);
 /* Waits for `stream` and reports TAHOE_ERR_HIP if a kernel flagged an internal error (a bounded
  * LDS wait of TILERING timing out); TAHOE_OK otherwise. */
 tahoe_status tahoe_forest_check(tahoe_forest *f, void *stream);
+/* Sizes the handle's device workspace for batches of up to `rows` rows (QRING keeps a 2-byte-per-value
+ * quantised copy of the batch).  Optional: predict grows the workspace on demand, which is the only
+ * case in which a predict call allocates (and synchronises the device). */
+tahoe_status tahoe_forest_reserve(tahoe_forest *f, size_t rows);
 /* Strategy the next predict will run (after AUTO resolution for `rows`). */
 int tahoe_forest_get_strategy(const tahoe_forest *f, size_t rows);
 
@@ -152,6 +160,8 @@ typedef struct {
     int top_levels;          /* top levels staged in LDS by TILEBLOCK */
     int tile_rows;           /* rows per TILEBLOCK tile: 128, 64, or 0 = strategy unavailable */
     int tileblock_lds_bytes; /* dynamic LDS of the TILEBLOCK kernel */
+    int qring_walkers;       /* walker waves of the QRING kernel; 0 = strategy unavailable */
+    int qring_lds_bytes;     /* dynamic LDS of the QRING kernel */
     int ring_rows;           /* rows per TILERING tile: 64, 128, or 0 = strategy unavailable */
     int tilering_lds_bytes;  /* dynamic LDS of the TILERING kernel */
 } tahoe_forest_info;

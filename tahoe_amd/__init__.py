@@ -24,5 +24,6 @@ from .capi import (  # noqa: F401
     STRATEGY_ROWTILE,
     STRATEGY_TILEBLOCK,
     STRATEGY_TILERING,
+    STRATEGY_QRING,
     STRATEGY_NAMES,
 )

@@ -32,8 +32,8 @@ lib = C.CDLL(LIB_PATH)
 
 # ---- constants mirrored from the header ----
 OUT_RAW, OUT_AVG, OUT_SIGMOID, OUT_THRESHOLD = 0x0, 0x1, 0x10, 0x100
-STRATEGY_AUTO, STRATEGY_DIRECT, STRATEGY_ROWTILE, STRATEGY_TILEBLOCK, STRATEGY_TILERING = 0, 1, 2, 3, 4
-STRATEGY_NAMES = {1: "direct", 2: "rowtile", 3: "tileblock", 4: "tilering"}
+STRATEGY_AUTO, STRATEGY_DIRECT, STRATEGY_ROWTILE, STRATEGY_TILEBLOCK, STRATEGY_TILERING, STRATEGY_QRING = range(6)
+STRATEGY_NAMES = {1: "direct", 2: "rowtile", 3: "tileblock", 4: "tilering", 5: "qring"}
 STATUS_NAMES = {
     0: "TAHOE_OK",
     1: "TAHOE_ERR_INVALID_ARG",
@@ -81,6 +81,8 @@ class ForestInfo(C.Structure):
         ("top_levels", C.c_int),
         ("tile_rows", C.c_int),
         ("tileblock_lds_bytes", C.c_int),
+        ("qring_walkers", C.c_int),
+        ("qring_lds_bytes", C.c_int),
         ("ring_rows", C.c_int),
         ("tilering_lds_bytes", C.c_int),
     ]
@@ -114,6 +116,7 @@ _PROTOS = {
     "tahoe_forest_set_strategy": (_i, [_vp, _i]),
     "tahoe_forest_get_strategy": (_i, [_vp, _sz]),
     "tahoe_forest_check": (_i, [_vp, _vp]),
+    "tahoe_forest_reserve": (_i, [_vp, _sz]),
     "tahoe_forest_get_info": (_i, [_vp, C.POINTER(ForestInfo)]),
     "tahoe_forest_set_profiling": (_i, [_vp, _i]),
     "tahoe_forest_kernel_times": (_i, [_vp, _vp, _i, C.POINTER(_i)]),
@@ -297,6 +300,9 @@ class Forest:
 
     def get_strategy(self, rows: int) -> int:
         return lib.tahoe_forest_get_strategy(self._h, rows)
+
+    def reserve(self, rows: int) -> None:
+        _check(lib.tahoe_forest_reserve(self._h, rows), "tahoe_forest_reserve")
 
     def check(self, stream=None) -> None:
         """Waits for the stream; raises if a kernel flagged an internal error."""

@@ -33,65 +33,7 @@
 #include <new>
 #include <vector>
 
-#include "common.h"
-
-namespace tahoe {
-
-struct InnerNode {
-    float thr;
-    uint32_t meta;  // fid | def_left << 31
-};
-static_assert(sizeof(InnerNode) == 8, "InnerNode must be 8 bytes");
-
-constexpr int kBlock = 256;             // threads per workgroup of DIRECT / ROWTILE (4 waves)
-constexpr int kWaves = kBlock / 64;
-constexpr int kTileRows = 64;           // rows per ROWTILE workgroup = one wave of lanes
-constexpr int kMaxLdsLevels = 8;        // ROWTILE: top levels staged per wave (255 nodes = 2040 B)
-constexpr float kMissingEps = 1.0e-6f;  // BaseTahoeTest.h:451
-
-// TILEBLOCK geometry
-constexpr int kTopLevelsMax = 10;       // top levels kept in LDS (1023 nodes: 4 KiB thr + 2 KiB meta)
-constexpr int kSlots = 4;               // trees in flight per workgroup
-constexpr int kBlockFidBits = 9;        // bottom blocks pack 3 x (fid:9 | def_left:1) in one dword
-constexpr int kBlockMaxCols = 1 << kBlockFidBits;
-
-static inline int align16(int x) { return (x + 15) & ~15; }
-static inline int top_nodes(int top_levels) { return (1 << top_levels) - 1; }
-// A staged top is indexed by 1-based heap position (entry 0 unused), so that the two children of
-// position i form the aligned pair (2i, 2i+1).
-static inline int top_thr_bytes(int top_levels) { return align16((top_nodes(top_levels) + 1) * 4); }
-static inline int top_stride_bytes(int top_levels)
-{
-    return top_thr_bytes(top_levels) + align16((top_nodes(top_levels) + 1) * 2);
-}
-
-}  // namespace tahoe
-
-struct tahoe_forest {
-    tahoe_forest_params p{};
-    int depth = 0;        // De: depth of the normalised trees, max(p.depth, 2)
-    size_t n_inner = 0;   // 2^De - 1
-    size_t n_leaf = 0;    // 2^De
-    int bits_bytes = 0;
-    int strategy = TAHOE_STRATEGY_AUTO;
-    int device = 0;
-    int num_cus = 0;
-    int lds_limit = 0;
-    int lds_levels = 0;   // ROWTILE
-    int top_levels = 0;   // TILEBLOCK: levels in LDS, min(De - 2, 10)
-    bool has_blocks = false;
-    tahoe::InnerNode *inner = nullptr;
-    float *leaf_val = nullptr;
-    uint32_t *leaf_orig = nullptr;
-    unsigned char *top = nullptr;  // [T][top_stride]
-    uint4 *blocks = nullptr;       // [T][2^(De-2)][2]
-    int *error_flag = nullptr;     // set by TILERING if a bounded spin ever times out
-    size_t device_bytes = 0;
-    // Profiling: one hipEvent pair per traversal launch, read back after the stream has drained.
-    bool profiling = false;
-    std::vector<hipEvent_t> ev_start, ev_stop;
-    size_t prof_count = 0;  // launches recorded since profiling was (re-)enabled
-};
+#include "forest_internal.h"
 
 namespace tahoe {
 
@@ -762,6 +704,7 @@ static int tilering_rows(const tahoe_forest *f)
 static int resolve_strategy(const tahoe_forest *f, size_t /*rows*/)
 {
     if (f->strategy != TAHOE_STRATEGY_AUTO) return f->strategy;
+    if (qring_walkers(f) > 0) return TAHOE_STRATEGY_QRING;
     if (tilering_rows(f) > 0) return TAHOE_STRATEGY_TILERING;
     if (tileblock_rows(f) > 0) return TAHOE_STRATEGY_TILEBLOCK;
     return rowtile_fits(f) ? TAHOE_STRATEGY_ROWTILE : TAHOE_STRATEGY_DIRECT;
@@ -813,6 +756,9 @@ static tahoe_status launch_traversal(tahoe_forest *f, float *sums, uint32_t *lea
     if (f->p.num_trees == 0) {
         // Nothing to walk: sums are zero (an empty j-loop in predict_on_cpu).
         if (sums) TAHOE_HIP_TRY(hipMemsetAsync(sums, 0, rows * sizeof(float), stream));
+    } else if (strategy == TAHOE_STRATEGY_QRING) {
+        const tahoe_status qs = qring_launch(f, sums, leaf_out, data, rows, stream);
+        if (qs != TAHOE_OK) return qs;
     } else if (strategy == TAHOE_STRATEGY_TILERING) {
         const int tr = tilering_rows(f);
         if (tr == 0)
@@ -963,6 +909,7 @@ tahoe_status tahoe_forest_create(tahoe_forest **out, const tahoe_dense_node *nod
     std::vector<float> h_leaf(T * f->n_leaf);
     std::vector<uint32_t> h_orig(T * f->n_leaf);
     std::vector<int64_t> inherit(all_nodes);
+    std::vector<unsigned char> h_real(T * f->n_inner, 0);  // heap records that exist in the original tree
     int max_fid = 0;
     for (size_t t = 0; t < T; ++t) {
         const tahoe_dense_node *tree = nodes + t * src_nodes;
@@ -1002,6 +949,7 @@ tahoe_status tahoe_forest_create(tahoe_forest **out, const tahoe_dense_node *nod
                 } else {
                     n.thr = value;
                     n.meta = (uint32_t)fid | (def_left ? 0x80000000u : 0u);
+                    h_real[t * f->n_inner + i] = 1;
                 }
             } else {
                 const size_t b = t * f->n_leaf + (i - f->n_inner);
@@ -1074,10 +1022,15 @@ tahoe_status tahoe_forest_create(tahoe_forest **out, const tahoe_dense_node *nod
         if ((e = allow_lds(&tileblock_kernel<128, false>, lds)) != hipSuccess) return bail(e, "hipFuncSetAttribute(tileblock)");
         if ((e = allow_lds(&tileblock_kernel<128, true>, lds)) != hipSuccess) return bail(e, "hipFuncSetAttribute(tileblock)");
     }
-    if (f->has_blocks) {
-        if ((e = hipMalloc(reinterpret_cast<void **>(&f->error_flag), sizeof(int))) != hipSuccess)
-            return bail(e, "hipMalloc(error_flag)");
-        if ((e = hipMemset(f->error_flag, 0, sizeof(int))) != hipSuccess) return bail(e, "hipMemset(error_flag)");
+    if ((e = hipMalloc(reinterpret_cast<void **>(&f->error_flag), sizeof(int))) != hipSuccess)
+        return bail(e, "hipMalloc(error_flag)");
+    if ((e = hipMemset(f->error_flag, 0, sizeof(int))) != hipSuccess) return bail(e, "hipMemset(error_flag)");
+    {
+        const tahoe_status qs = qring_build(f, h_inner, h_real, h_leaf);
+        if (qs != TAHOE_OK) {
+            tahoe_forest_destroy(f);
+            return qs;
+        }
     }
     if (f->has_blocks && tilering_lds_bytes(f, 64) <= f->lds_limit) {
         const long long lds = tilering_lds_bytes(f, 64);
@@ -1107,6 +1060,7 @@ void tahoe_forest_destroy(tahoe_forest *f)
     if (f->top) (void)hipFree(f->top);
     if (f->blocks) (void)hipFree(f->blocks);
     if (f->error_flag) (void)hipFree(f->error_flag);
+    qring_destroy(f);
     for (hipEvent_t e : f->ev_start) (void)hipEventDestroy(e);
     for (hipEvent_t e : f->ev_stop) (void)hipEventDestroy(e);
     delete f;
@@ -1149,7 +1103,7 @@ tahoe_status tahoe_transform_preds(float *preds_dev, size_t rows, int output, in
 tahoe_status tahoe_forest_set_strategy(tahoe_forest *f, int strategy)
 {
     if (!f) return fail(TAHOE_ERR_INVALID_ARG, "null forest");
-    if (strategy < TAHOE_STRATEGY_AUTO || strategy > TAHOE_STRATEGY_TILERING)
+    if (strategy < TAHOE_STRATEGY_AUTO || strategy > TAHOE_STRATEGY_QRING)
         return fail(TAHOE_ERR_INVALID_ARG, "unknown strategy %d", strategy);
     if (strategy == TAHOE_STRATEGY_ROWTILE && !rowtile_fits(f))
         return fail(TAHOE_ERR_UNSUPPORTED, "ROWTILE needs %d B of LDS for %d columns; device offers %d",
@@ -1160,8 +1114,17 @@ tahoe_status tahoe_forest_set_strategy(tahoe_forest *f, int strategy)
     if (strategy == TAHOE_STRATEGY_TILERING && tilering_rows(f) == 0)
         return fail(TAHOE_ERR_UNSUPPORTED, "TILERING needs num_cols <= %d and a 64-row tile that fits %d B of LDS",
                     kBlockMaxCols, f->lds_limit);
+    if (strategy == TAHOE_STRATEGY_QRING && qring_walkers(f) == 0)
+        return fail(TAHOE_ERR_UNSUPPORTED,
+                    "QRING needs <= 32767 distinct thresholds per feature, num_cols <= 32767 and a 128-row u16 tile in LDS");
     f->strategy = strategy;
     return TAHOE_OK;
+}
+
+tahoe_status tahoe_forest_reserve(tahoe_forest *f, size_t rows)
+{
+    if (!f) return fail(TAHOE_ERR_INVALID_ARG, "null forest");
+    return qring_reserve(f, rows);
 }
 
 tahoe_status tahoe_forest_check(tahoe_forest *f, void *stream)
@@ -1171,7 +1134,7 @@ tahoe_status tahoe_forest_check(tahoe_forest *f, void *stream)
     if (f->error_flag) {
         int flag = 0;
         TAHOE_HIP_TRY(hipMemcpy(&flag, f->error_flag, sizeof(int), hipMemcpyDeviceToHost));
-        if (flag != 0) return fail(TAHOE_ERR_HIP, "TILERING: a bounded LDS ring wait timed out; results are invalid");
+        if (flag != 0) return fail(TAHOE_ERR_HIP, "a bounded LDS ring wait timed out (TILERING/QRING); results are invalid");
     }
     return TAHOE_OK;
 }
@@ -1194,6 +1157,8 @@ tahoe_status tahoe_forest_get_info(const tahoe_forest *f, tahoe_forest_info *inf
     info->top_levels = f->top_levels;
     info->tile_rows = tileblock_rows(f);
     info->tileblock_lds_bytes = info->tile_rows ? (int)tileblock_lds_bytes(f, info->tile_rows) : 0;
+    info->qring_walkers = qring_walkers(f);
+    info->qring_lds_bytes = (int)qring_lds_bytes(f);
     info->ring_rows = tilering_rows(f);
     info->tilering_lds_bytes = info->ring_rows ? (int)tilering_lds_bytes(f, info->ring_rows) : 0;
     return TAHOE_OK;

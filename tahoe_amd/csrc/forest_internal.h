@@ -1,0 +1,85 @@
+// Definitions shared by the translation units that implement the forest operator (forest.hip,
+// qring.hip).  Internal: not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <vector>
+
+#include "common.h"
+
+struct tahoe_qstate;  // quantised views + workspace, owned by qring.hip
+
+namespace tahoe {
+
+struct InnerNode {
+    float thr;
+    uint32_t meta;  // fid | def_left << 31
+};
+static_assert(sizeof(InnerNode) == 8, "InnerNode must be 8 bytes");
+
+constexpr int kBlock = 256;             // threads per workgroup of DIRECT / ROWTILE (4 waves)
+constexpr int kWaves = kBlock / 64;
+constexpr int kTileRows = 64;           // rows per ROWTILE workgroup = one wave of lanes
+constexpr int kMaxLdsLevels = 8;        // ROWTILE: top levels staged per wave (255 nodes = 2040 B)
+constexpr float kMissingEps = 1.0e-6f;  // BaseTahoeTest.h:451
+
+// TILEBLOCK geometry
+constexpr int kTopLevelsMax = 10;       // top levels kept in LDS (1023 nodes: 4 KiB thr + 2 KiB meta)
+constexpr int kSlots = 4;               // trees in flight per workgroup
+constexpr int kBlockFidBits = 9;        // bottom blocks pack 3 x (fid:9 | def_left:1) in one dword
+constexpr int kBlockMaxCols = 1 << kBlockFidBits;
+
+static inline int align16(int x) { return (x + 15) & ~15; }
+static inline int top_nodes(int top_levels) { return (1 << top_levels) - 1; }
+// A staged top is indexed by 1-based heap position (entry 0 unused), so that the two children of
+// position i form the aligned pair (2i, 2i+1).
+static inline int top_thr_bytes(int top_levels) { return align16((top_nodes(top_levels) + 1) * 4); }
+static inline int top_stride_bytes(int top_levels)
+{
+    return top_thr_bytes(top_levels) + align16((top_nodes(top_levels) + 1) * 2);
+}
+
+}  // namespace tahoe
+
+struct tahoe_forest {
+    tahoe_forest_params p{};
+    int depth = 0;        // De: depth of the normalised trees, max(p.depth, 2)
+    size_t n_inner = 0;   // 2^De - 1
+    size_t n_leaf = 0;    // 2^De
+    int bits_bytes = 0;
+    int strategy = TAHOE_STRATEGY_AUTO;
+    int device = 0;
+    int num_cus = 0;
+    int lds_limit = 0;
+    int lds_levels = 0;   // ROWTILE
+    int top_levels = 0;   // TILEBLOCK: levels in LDS, min(De - 2, 10)
+    bool has_blocks = false;
+    tahoe::InnerNode *inner = nullptr;
+    float *leaf_val = nullptr;
+    uint32_t *leaf_orig = nullptr;
+    unsigned char *top = nullptr;  // [T][top_stride]
+    uint4 *blocks = nullptr;       // [T][2^(De-2)][2]
+    int *error_flag = nullptr;     // set by TILERING if a bounded spin ever times out
+    tahoe_qstate *q = nullptr;     // QRING: rank-quantised forest + row workspace (qring.hip)
+    size_t device_bytes = 0;
+    // Profiling: one hipEvent pair per traversal launch, read back after the stream has drained.
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_start, ev_stop;
+    size_t prof_count = 0;  // launches recorded since profiling was (re-)enabled
+};
+
+namespace tahoe {
+
+// QRING entry points (qring.hip).  h_real[i] != 0 marks heap records that exist in the original tree
+// (padding below an early leaf is not real and contributes no threshold).
+tahoe_status qring_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner, const std::vector<unsigned char> &h_real,
+                         const std::vector<float> &h_leaf);
+void qring_destroy(tahoe_forest *f);
+int qring_walkers(const tahoe_forest *f);  // walker waves the kernel would use; 0 = strategy unavailable
+long long qring_lds_bytes(const tahoe_forest *f);
+tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, const float *data, size_t rows,
+                          hipStream_t stream);
+tahoe_status qring_reserve(tahoe_forest *f, size_t rows);
+
+}  // namespace tahoe

@@ -1,0 +1,594 @@
+// QRING: the traversal on rank-quantised features -- exact, and half the LDS bytes.
+//
+// Idea.  A walk only ever compares a feature value x with thresholds of that same feature.  Let
+// tab_f be the sorted distinct (finite or infinite, non-NaN) thresholds the forest uses on feature f,
+// and code_f(x) = #{ e in tab_f : e <= x } (float32 compares; 0 for NaN).  A node with threshold
+// tab_f[p] then satisfies   x >= thr  <=>  code_f(x) >= p + 1   for every float x, NaN included, so
+// the branch rule of infer_one_tree (BaseTahoeTest.h:450-453) is reproduced bit for bit with 16-bit
+// integers: the row tile and the node records shrink to half, twice as many rows and three times as
+// many trees fit in LDS, and one ds_read_b64 fetches both children of a node.
+//   x code    u16: 0..n_f, or 0xFFFF when |x - missing| <= 1e-6 (float32)   (missing takes !def_left)
+//   node      u32: threshold code (1..n_f; 0xFFFF for a NaN threshold: never >=) | fid << 16 | def_left << 31
+//   top       [t][2^L] u32, 1-based heap positions (children of i = the aligned pair 2i, 2i+1), L <= 10
+//   block     [t][2^(De-2)] 32 B = {node0, node1, node2, 0} {leaf0..3 f32}: last two levels + leaves
+// Requires n_f <= 32767 for every feature (the per-feature table must fit LDS in the quantise kernel)
+// and num_cols <= 32767; otherwise the strategy is unavailable and the float32 strategies serve.
+//
+// Per predict: (1) quantize_kernel turns the row-major float32 batch into 128-row tiles
+// xq[tile][fid][128] u16 (rows permuted inside a column so that lane = row reads are bank-conflict
+// free), one binary search per value in an LDS-resident table; (2) qring_kernel walks: per CU one
+// workgroup = NWALK walker waves (private top slot each, two 64-row chains per lane, next top
+// prefetched in registers, no barrier in the tree loop) + one consumer wave that adds the leaf values
+// in tree order through an LDS ring -- the float32 sums stay bit-identical to predict_on_cpu.
+//
+// Replaces, like forest.hip: the adaptive-format walkers/kernels of Struct.h:953-1704 and the
+// layout build of Struct.h:1756-1986 (whose char/short/int "adaptive" widths compress only the
+// fid/flag word; here the threshold is compressed too, losslessly).
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "forest_internal.h"
+
+struct tahoe_qstate {
+    int top_levels = 0;
+    int max_table = 0;            // max n_f
+    bool have_mid = false;        // De - 2 > top_levels: heap of quantised nodes for the middle levels
+    float *tables = nullptr;      // concatenated tab_f
+    int *offsets = nullptr;       // [cols + 1]
+    uint32_t *top = nullptr;      // [T][2^L]
+    uint4 *blocks = nullptr;      // [T][2^(De-2)][2]
+    uint32_t *qinner = nullptr;   // [T][2^De - 1] (only when have_mid)
+    uint16_t *xq = nullptr;       // workspace: quantised tiles
+    size_t xq_rows = 0;           // rows the workspace holds
+    int top_stride = 0;           // u32 entries per tree in `top` (>= 4)
+};
+
+namespace tahoe {
+
+constexpr int kQRows = 128;                 // rows per tile
+constexpr int kQRing = 16;                  // ring entries (trees)
+constexpr int kQBatch = 8;                  // trees the consumer takes per poll
+constexpr int kQSpinLimit = 1 << 22;
+constexpr int kQSlotBytes = 4096;            // LDS per walker: a 10-level top (2^10 u32)
+constexpr int kQMaxTable = 32767;
+constexpr int kQuantRowsPerBlock = 32768;   // rows one quantise workgroup converts for its feature
+constexpr int kQuantThreads = 512;
+constexpr uint32_t kCodeMissing = 0xFFFFu;
+
+// position of tile row r (0..127) inside a feature column of 128 u16: within a 32-lane group the
+// rows land in 32 different LDS banks (two rows per dword come from different groups)
+__host__ __device__ __forceinline__ int qrow_pos(int r) { return ((r & 31) << 1) | ((r >> 5) & 1) | ((r >> 6) << 6); }
+
+// ------------------------------------------------------------------------------------------------
+// (1) float32 rows -> u16 codes.  One workgroup = one feature x kQuantRowsPerBlock rows; the
+// feature's table sits in LDS; consecutive workgroups take consecutive features of the same rows, so
+// the 64-byte lines of the row-major input are shared through L2.
+__global__ void __launch_bounds__(kQuantThreads) quantize_kernel(const float *__restrict__ data, const float *__restrict__ tables,
+                                                       const int *__restrict__ offsets, uint16_t *__restrict__ xq,
+                                                       size_t rows, int cols, float missing)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *tab = reinterpret_cast<float *>(smem);
+    const int f = blockIdx.x % cols;
+    const size_t chunk = blockIdx.x / cols;
+    const int base = offsets[f];
+    const int n = offsets[f + 1] - base;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) tab[i] = tables[base + i];
+    __syncthreads();
+    int top_step = 1;
+    while (top_step * 2 <= n) top_step *= 2;  // largest power of two <= n (1 when n <= 1)
+    const size_t r0 = chunk * kQuantRowsPerBlock;
+    const size_t r1 = min(rows, r0 + (size_t)kQuantRowsPerBlock);
+    // Four rows per thread and iteration: four independent load + search chains hide the LDS latency of
+    // the ~15 dependent probes each search makes.
+    constexpr int U = 4;
+    for (size_t rb = r0 + threadIdx.x; rb < r1; rb += (size_t)blockDim.x * U) {
+        float x[U];
+        int cnt[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t r = min(rb + (size_t)u * blockDim.x, r1 - 1);  // clamped: in bounds, result unused
+            x[u] = data[r * (size_t)cols + f];
+            cnt[u] = 0;
+        }
+        for (int step = top_step; step >= 1; step >>= 1) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int probe = cnt[u] + step;  // count of table entries <= x, branch-free; NaN -> 0
+                if (probe <= n && tab[probe - 1] <= x[u]) cnt[u] = probe;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t r = rb + (size_t)u * blockDim.x;
+            if (r < r1) {
+                const uint32_t code = (fabsf(x[u] - missing) <= kMissingEps) ? kCodeMissing : (uint32_t)cnt[u];
+                xq[(r / kQRows) * ((size_t)cols * kQRows) + (size_t)f * kQRows + qrow_pos((int)(r % kQRows))] =
+                    (uint16_t)code;
+            }
+        }
+    }
+}
+
+// Ring flags: relaxed workgroup-scope accesses (plain ds_read/ds_write that the compiler neither caches
+// in a register nor reorders across the asm memory barriers around them).
+__device__ __forceinline__ uint32_t lds_flag_load(const uint32_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_flag_store(uint32_t *p, uint32_t v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// The branch rule on codes: right <=> (missing ? !def_left : code(x) >= code(thr)).  Written on wave
+// masks: three v_cmp into SGPR pairs, three SALU ops, and the result is used directly as the lane
+// predicate of v_cndmask / v_addc (hipcc's ?: form materialises both booleans in VGPRs: 6 more VALU).
+__device__ __forceinline__ uint64_t q_right_mask(uint32_t xc, uint32_t node)
+{
+    const uint64_t ge = __builtin_amdgcn_uicmp(xc, node & 0xFFFFu, 35 /* ICMP_UGE */);
+    const uint64_t ms = __builtin_amdgcn_uicmp(xc, kCodeMissing, 32 /* ICMP_EQ */);
+    const uint64_t ndl = __builtin_amdgcn_sicmp((int)node, -1, 38 /* ICMP_SGT: bit 31 (def_left) clear */);
+    return (ge & ~ms) | (ms & ndl);
+}
+__device__ __forceinline__ bool q_go_right(uint32_t xc, uint32_t node)
+{
+    return __builtin_amdgcn_inverse_ballot_w64(q_right_mask(xc, node));
+}
+// i <- 2i + (lane's bit of mask): one v_addc with the mask as carry-in
+__device__ __forceinline__ uint32_t q_descend(uint32_t i, uint64_t right_mask)
+{
+    uint32_t r;
+    uint64_t carry_out;
+    asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(r), "=&s"(carry_out) : "v"(i), "s"(right_mask));
+    return r;
+}
+// byte offset of the u16 code of feature fid(node) for the row at byte position pos2 of a column:
+// (fid << 8) | pos2, two VALU (shift, and-or) instead of the three hipcc emits for the C expression
+__device__ __forceinline__ uint32_t q_xoff(uint32_t node, uint32_t pos2)
+{
+    uint32_t r;
+    asm("v_lshrrev_b32 %0, 8, %1\n\tv_and_or_b32 %0, %0, %2, %3" : "=&v"(r) : "v"(node), "s"(0x7fff00u), "v"(pos2));
+    return r;
+}
+__device__ __forceinline__ uint32_t q_xread(const uint16_t *tile, uint32_t node, uint32_t pos2)
+{
+    return *reinterpret_cast<const uint16_t *>(reinterpret_cast<const unsigned char *>(tile) + q_xoff(node, pos2));
+}
+
+// ------------------------------------------------------------------------------------------------
+// (2) the walk.  Dynamic LDS: tile [cols][128] u16 | NWALK slots of (4 << L) bytes | ring [16][128] f32 |
+// ready[16] | consumed.
+template <int NWALK, bool WRITE_LEAF>
+__global__ void __launch_bounds__((NWALK + 1) * 64)
+    qring_kernel(const uint16_t *__restrict__ xq, const uint32_t *__restrict__ top, const uint4 *__restrict__ blocks,
+                 const uint32_t *__restrict__ qinner, const uint32_t *__restrict__ leaf_orig, float *__restrict__ sums,
+                 uint32_t *__restrict__ leaf_out, size_t rows, int cols, int num_trees, int depth, int top_levels,
+                 int top_stride, int *__restrict__ error_flag)
+{
+    constexpr int K = kQRows / 64;  // two 64-row chains per walker lane
+    constexpr int NT = (NWALK + 1) * 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int slot_bytes = kQSlotBytes;  // fixed 4 KiB slot (2^10 u32): no size-dependent branches in the loop
+
+    uint16_t *tile = reinterpret_cast<uint16_t *>(smem);
+    unsigned char *slots = smem + (size_t)cols * kQRows * sizeof(uint16_t);
+    float *ring_vals = reinterpret_cast<float *>(slots + (size_t)NWALK * slot_bytes);
+    uint32_t *ring_ready = reinterpret_cast<uint32_t *>(ring_vals + kQRing * kQRows);
+    uint32_t *consumed = ring_ready + kQRing;
+
+    const size_t row0 = (size_t)blockIdx.x * kQRows;
+
+    // ---- stage the quantised tile (already in LDS order): straight 16-byte copies ----
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(xq + (size_t)blockIdx.x * ((size_t)cols * kQRows));
+        uint4 *dst = reinterpret_cast<uint4 *>(tile);
+        const int n16 = cols * kQRows * 2 / 16;
+        for (int e = tid; e < n16; e += NT) dst[e] = src[e];
+    }
+    if (tid < kQRing) ring_ready[tid] = 0u;
+    if (tid == kQRing) *consumed = 0u;
+
+    if (wave == NWALK) {
+        // ================= consumer: ordered accumulation =================
+        __syncthreads();
+        float sum[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) sum[k] = 0.0f;
+        bool dead = false;
+        for (int t0 = 0; t0 < num_trees && !dead; t0 += kQBatch) {
+            const int nb = min(kQBatch, num_trees - t0);
+            int spins = 0;
+            for (;;) {
+                const bool ok = lane >= nb || lds_flag_load(&ring_ready[(t0 + lane) % kQRing]) == (uint32_t)(t0 + lane + 1);
+                if (__ballot(ok) == ~0ull) break;
+                if (++spins > kQSpinLimit) {
+                    dead = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (dead) break;
+            asm volatile("" ::: "memory");  // the values are read after the flags
+            for (int j = 0; j < nb; ++j) {
+                const int e = (t0 + j) % kQRing;
+#pragma unroll
+                for (int k = 0; k < K; ++k) sum[k] += ring_vals[e * kQRows + k * 64 + lane];  // tree order
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) lds_flag_store(consumed, (uint32_t)(t0 + nb));
+        }
+        if (dead && lane == 0) atomicOr(error_flag, 1);
+        if (sums) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const size_t orow = row0 + k * 64 + lane;
+                if (orow < rows) sums[orow] = sum[k];
+            }
+        }
+        return;
+    }
+
+    // ================= walkers =================
+    uint32_t *slot = reinterpret_cast<uint32_t *>(slots + (size_t)wave * slot_bytes);
+    const int n_chunks = (top_stride * 4) >> 4;  // 16-byte chunks of a top in global memory (<= 256)
+    uint4 pf0 = {}, pf1 = {}, pf2 = {}, pf3 = {};   // named registers (an indexed array would go to scratch)
+    auto prefetch_top = [&](int t) {
+        const uint4 *g = reinterpret_cast<const uint4 *>(top + (size_t)t * top_stride);
+        const int last = n_chunks - 1;  // clamped: branch-free and in bounds
+        pf0 = g[min(0 * 64 + lane, last)];
+        pf1 = g[min(1 * 64 + lane, last)];
+        pf2 = g[min(2 * 64 + lane, last)];
+        pf3 = g[min(3 * 64 + lane, last)];
+    };
+    // Unconditional stores (a smaller top just rewrites its last chunk into unused slot space): with
+    // per-lane conditions hipcc branches around each store AND its s_waitcnt, leaves the load "pending" on
+    // the skipped path and then waits for the newest gathers at the loop latch.
+    auto commit_top = [&]() {
+        uint4 *s = reinterpret_cast<uint4 *>(slot);
+        s[0 * 64 + lane] = pf0;
+        s[1 * 64 + lane] = pf1;
+        s[2 * 64 + lane] = pf2;
+        s[3 * 64 + lane] = pf3;
+    };
+    if (wave < num_trees) {
+        prefetch_top(wave);
+        commit_top();
+    }
+    __syncthreads();  // the tile, the ring state and (own wave) the first top are in LDS
+
+    uint32_t pos[K];  // byte position of this lane's row inside a 256-byte feature column, per chain
+#pragma unroll
+    for (int k = 0; k < K; ++k) pos[k] = 2u * (uint32_t)qrow_pos(k * 64 + lane);
+    const size_t n_inner = ((size_t)1 << depth) - 1;
+    const uint32_t n_blocks = 1u << (depth - 2);
+    const uint32_t first_block_node = n_blocks - 1;
+    bool dead = false;
+    // last two levels + leaf of tree t from its 32-byte blocks, then the hand-over to the consumer
+    auto finish = [&](int t, const uint4 (&na)[K], const uint4 (&nb)[K], const uint32_t (&bs)[K]) {
+        float v[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            // two dependent steps (the kernel is VALU-bound: this is ~half the instructions of evaluating
+            // both second-level nodes)
+            const bool c0 = q_go_right(q_xread(tile, na[k].x, pos[k]), na[k].x);
+            const uint32_t n1 = c0 ? na[k].z : na[k].y;
+            const bool c1 = q_go_right(q_xread(tile, n1, pos[k]), n1);
+            const uint32_t lo = c0 ? nb[k].z : nb[k].x, hi = c0 ? nb[k].w : nb[k].y;
+            v[k] = __uint_as_float(c1 ? hi : lo);
+            if (WRITE_LEAF) {
+                const size_t row = row0 + k * 64 + lane;
+                if (row < rows)
+                    leaf_out[row * (size_t)num_trees + t] =
+                        leaf_orig[(size_t)t * ((size_t)n_blocks * 4) + (size_t)bs[k] * 4 + 2 * (c0 ? 1 : 0) + (c1 ? 1 : 0)];
+            }
+        }
+        if (t >= kQRing) {  // ring entry still in use by tree t - kQRing?
+            int spins = 0;
+            while (lds_flag_load(consumed) < (uint32_t)(t - kQRing + 1)) {
+                if (++spins > kQSpinLimit) {
+                    dead = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        const int e = t % kQRing;
+#pragma unroll
+        for (int k = 0; k < K; ++k) ring_vals[e * kQRows + k * 64 + lane] = v[k];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // values before the flag (in-order LDS)
+        if (lane == 0) lds_flag_store(&ring_ready[e], (uint32_t)(t + 1));
+    };
+    int t_p = -1;  // tree whose bottom blocks are in flight
+    uint4 na_p[K] = {}, nb_p[K] = {};
+    uint32_t bsel_p[K] = {};
+    for (int t = wave; t < num_trees && !dead; t += NWALK) {
+        const bool more = t + NWALK < num_trees;
+        if (more) prefetch_top(t + NWALK);
+        uint32_t i[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) i[k] = 1;
+        if (top_levels > 0) {
+            uint32_t node[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) node[k] = slot[1];
+            for (int l = 0; l < top_levels - 1; ++l) {
+                uint32_t xc[K];
+                uint2 pr[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    xc[k] = q_xread(tile, node[k], pos[k]);
+                    pr[k] = *reinterpret_cast<const uint2 *>(&slot[2 * i[k]]);  // children 2i, 2i+1
+                }
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const uint64_t cm = q_right_mask(xc[k], node[k]);
+                    i[k] = q_descend(i[k], cm);
+                    node[k] = __builtin_amdgcn_inverse_ballot_w64(cm) ? pr[k].y : pr[k].x;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const uint32_t xc = q_xread(tile, node[k], pos[k]);
+                i[k] = q_descend(i[k], q_right_mask(xc, node[k]));
+            }
+        }
+        uint32_t bsel[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            uint32_t idx = i[k] - 1;  // 0-based heap index on level top_levels
+            if (top_levels < depth - 2) {  // deep trees only (De > 12): quantised heap nodes from global memory
+                const uint32_t *tree = qinner + (size_t)t * n_inner;
+                for (int l = top_levels; l < depth - 2; ++l) {
+                    const uint32_t n = tree[idx];
+                    const uint32_t xc = q_xread(tile, n, pos[k]);
+                    idx = 2u * idx + 1u + (q_go_right(xc, n) ? 1u : 0u);
+                }
+            }
+            bsel[k] = idx - first_block_node;
+        }
+        // ---- software pipeline: finish the PREVIOUS tree (its bottom-block gathers were issued one
+        // iteration ago and have been flying under this top walk), then issue this tree's gathers
+        // into the same registers ----
+        if (t_p >= 0) finish(t_p, na_p, nb_p, bsel_p);
+        t_p = t;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint4 *bp = blocks + ((size_t)t * n_blocks + bsel[k]) * 2;
+            na_p[k] = bp[0];  // node0, node1, node2, 0
+            nb_p[k] = bp[1];  // four leaf values
+            bsel_p[k] = bsel[k];
+        }
+        if (more) commit_top();  // this wave's reads of its slot are done (in-order LDS)
+    }
+    if (t_p >= 0 && !dead) finish(t_p, na_p, nb_p, bsel_p);
+    if (dead && lane == 0) atomicOr(error_flag, 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+static long long qring_lds_for(const tahoe_forest *f, int nwalk)
+{
+    return (long long)f->p.num_cols * kQRows * 2 + (long long)nwalk * kQSlotBytes + (long long)kQRing * kQRows * 4 +
+           (kQRing + 1) * 4LL;
+}
+
+int qring_walkers(const tahoe_forest *f)
+{
+    if (!f->q) return 0;
+    static const int options[] = {15, 12, 8, 4};
+    if (const char *e = getenv("TAHOE_QRING_WALKERS")) {  // tuning knob for experiments
+        const int want = atoi(e);
+        for (int n : options)
+            if (n == want && qring_lds_for(f, n) <= f->lds_limit) return n;
+    }
+    for (int n : options)
+        if (qring_lds_for(f, n) <= f->lds_limit) return n;
+    return 0;
+}
+
+long long qring_lds_bytes(const tahoe_forest *f)
+{
+    const int n = qring_walkers(f);
+    return n ? qring_lds_for(f, n) : 0;
+}
+
+template <typename T>
+static hipError_t q_upload(T **dst, const T *src, size_t count, size_t *total)
+{
+    const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(dst), bytes);
+    if (e != hipSuccess) return e;
+    *total += bytes;
+    if (count) e = hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice);
+    return e;
+}
+
+template <int NWALK>
+static hipError_t q_allow(long long lds)
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&qring_kernel<NWALK, false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&qring_kernel<NWALK, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
+tahoe_status qring_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner, const std::vector<unsigned char> &h_real,
+                         const std::vector<float> &h_leaf)
+{
+    const int cols = f->p.num_cols;
+    const size_t T = (size_t)f->p.num_trees;
+    if (cols < 1 || cols > 32767 || T == 0) return TAHOE_OK;  // strategy simply unavailable
+    // ---- per-feature tables of distinct thresholds ----
+    std::vector<std::vector<float>> tab((size_t)cols);
+    for (size_t i = 0; i < h_inner.size(); ++i) {
+        if (!h_real[i] || std::isnan(h_inner[i].thr)) continue;
+        tab[h_inner[i].meta & 0x7fffffffu].push_back(h_inner[i].thr);
+    }
+    std::vector<int> offsets((size_t)cols + 1, 0);
+    int max_table = 0;
+    for (int c = 0; c < cols; ++c) {
+        auto &v = tab[c];
+        std::sort(v.begin(), v.end());                       // float order; -0.0f and 0.0f compare equal
+        v.erase(std::unique(v.begin(), v.end()), v.end());   // ... and collapse into one entry
+        max_table = std::max(max_table, (int)v.size());
+        offsets[c + 1] = offsets[c] + (int)v.size();
+    }
+    if (max_table > kQMaxTable) return TAHOE_OK;  // unavailable: the float32 strategies serve this forest
+    std::vector<float> tables((size_t)offsets[cols]);
+    for (int c = 0; c < cols; ++c) std::copy(tab[c].begin(), tab[c].end(), tables.begin() + offsets[c]);
+
+    // ---- node codes ----
+    auto encode = [&](const InnerNode &n, bool real) -> uint32_t {
+        if (!real) return 0u;  // padding below a leaf: both children carry the same value
+        const uint32_t fid = n.meta & 0x7fffffffu, dl = n.meta >> 31;
+        uint32_t code;
+        if (std::isnan(n.thr))
+            code = 0xFFFFu;  // x >= NaN is never true; a missing x still follows def_left
+        else {
+            const auto &v = tab[fid];
+            code = (uint32_t)(std::lower_bound(v.begin(), v.end(), n.thr) - v.begin()) + 1u;
+        }
+        return code | (fid << 16) | (dl << 31);
+    };
+    tahoe_qstate *q = new (std::nothrow) tahoe_qstate();
+    if (!q) return fail(TAHOE_ERR_NO_MEMORY, "qring_build");
+    f->q = q;
+    q->max_table = max_table;
+    const int De = f->depth;
+    q->top_levels = f->top_levels;
+    q->have_mid = De - 2 > q->top_levels;
+    const size_t n_inner = f->n_inner, n_leaf = f->n_leaf;
+    const size_t top_n = (size_t)1 << q->top_levels;  // entries per tree (entry 0 unused)
+    const size_t n_blocks = (size_t)1 << (De - 2);
+    const size_t first = n_blocks - 1;
+    std::vector<uint32_t> h_top(T * std::max<size_t>(top_n, 4), 0u);  // >= 16 bytes per tree
+    std::vector<uint4> h_blocks(T * n_blocks * 2);
+    std::vector<uint32_t> h_qinner(q->have_mid ? T * n_inner : 0);
+    const size_t top_stride = std::max<size_t>(top_n, 4);
+    q->top_stride = (int)top_stride;
+    for (size_t t = 0; t < T; ++t) {
+        const InnerNode *in = &h_inner[t * n_inner];
+        const unsigned char *re = &h_real[t * n_inner];
+        for (size_t i = 0; i + 1 < top_n; ++i) h_top[t * top_stride + i + 1] = encode(in[i], re[i] != 0);
+        if (q->have_mid)
+            for (size_t i = 0; i < n_inner; ++i) h_qinner[t * n_inner + i] = encode(in[i], re[i] != 0);
+        for (size_t b = 0; b < n_blocks; ++b) {
+            const size_t r = first + b, l = 2 * r + 1, rr = 2 * r + 2;
+            uint4 a, v;
+            a.x = encode(in[r], re[r] != 0);
+            a.y = encode(in[l], re[l] != 0);
+            a.z = encode(in[rr], re[rr] != 0);
+            a.w = 0u;
+            const float *lv = &h_leaf[t * n_leaf + 4 * b];
+            memcpy(&v.x, &lv[0], 4);
+            memcpy(&v.y, &lv[1], 4);
+            memcpy(&v.z, &lv[2], 4);
+            memcpy(&v.w, &lv[3], 4);
+            h_blocks[(t * n_blocks + b) * 2 + 0] = a;
+            h_blocks[(t * n_blocks + b) * 2 + 1] = v;
+        }
+    }
+    hipError_t e;
+    auto bad = [&](const char *what) { return fail(TAHOE_ERR_HIP, "qring_build: %s failed: %s", what, hipGetErrorString(e)); };
+    if ((e = q_upload(&q->tables, tables.data(), tables.size(), &f->device_bytes)) != hipSuccess) return bad("tables");
+    if ((e = q_upload(&q->offsets, offsets.data(), offsets.size(), &f->device_bytes)) != hipSuccess) return bad("offsets");
+    if ((e = q_upload(&q->top, h_top.data(), h_top.size(), &f->device_bytes)) != hipSuccess) return bad("top");
+    if ((e = q_upload(&q->blocks, h_blocks.data(), h_blocks.size(), &f->device_bytes)) != hipSuccess) return bad("blocks");
+    if (q->have_mid &&
+        (e = q_upload(&q->qinner, h_qinner.data(), h_qinner.size(), &f->device_bytes)) != hipSuccess)
+        return bad("qinner");
+    // kernels that need more than 64 KiB of dynamic LDS
+    if (qring_lds_for(f, 15) <= f->lds_limit && (e = q_allow<15>(qring_lds_for(f, 15))) != hipSuccess) return bad("attr15");
+    if (qring_lds_for(f, 12) <= f->lds_limit && (e = q_allow<12>(qring_lds_for(f, 12))) != hipSuccess) return bad("attr12");
+    if (qring_lds_for(f, 8) <= f->lds_limit && (e = q_allow<8>(qring_lds_for(f, 8))) != hipSuccess) return bad("attr8");
+    if (qring_lds_for(f, 4) <= f->lds_limit && (e = q_allow<4>(qring_lds_for(f, 4))) != hipSuccess) return bad("attr4");
+    if (max_table * 4 > 64 * 1024 &&
+        (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&quantize_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, kQMaxTable * 4)) != hipSuccess)
+        return bad("attr(quantize)");
+    return TAHOE_OK;
+}
+
+void qring_destroy(tahoe_forest *f)
+{
+    tahoe_qstate *q = f->q;
+    if (!q) return;
+    for (void *p : {(void *)q->tables, (void *)q->offsets, (void *)q->top, (void *)q->blocks, (void *)q->qinner,
+                    (void *)q->xq})
+        if (p) (void)hipFree(p);
+    delete q;
+    f->q = nullptr;
+}
+
+// The quantised copy of the batch lives in a grow-only workspace owned by the handle.
+tahoe_status qring_reserve(tahoe_forest *f, size_t rows)
+{
+    tahoe_qstate *q = f->q;
+    if (!q || qring_walkers(f) == 0) return TAHOE_OK;
+    const size_t tiles = (rows + kQRows - 1) / kQRows;
+    if (tiles * kQRows <= q->xq_rows) return TAHOE_OK;
+    if (q->xq) {
+        TAHOE_HIP_TRY(hipDeviceSynchronize());  // a previous launch may still read the old buffer
+        TAHOE_HIP_TRY(hipFree(q->xq));
+        f->device_bytes -= q->xq_rows * (size_t)f->p.num_cols * 2;
+        q->xq = nullptr;
+        q->xq_rows = 0;
+    }
+    const size_t bytes = tiles * kQRows * (size_t)f->p.num_cols * sizeof(uint16_t);
+    TAHOE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&q->xq), bytes));
+    q->xq_rows = tiles * kQRows;
+    f->device_bytes += bytes;
+    return TAHOE_OK;
+}
+
+template <int NWALK>
+static void q_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, size_t rows, hipStream_t stream)
+{
+    tahoe_qstate *q = f->q;
+    const unsigned grid = (unsigned)((rows + kQRows - 1) / kQRows);
+    const int lds = (int)qring_lds_for(f, NWALK);
+    if (leaf_out)
+        hipLaunchKernelGGL((qring_kernel<NWALK, true>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, q->top,
+                           q->blocks, q->qinner, f->leaf_orig, sums, leaf_out, rows, f->p.num_cols, f->p.num_trees,
+                           f->depth, q->top_levels, q->top_stride, f->error_flag);
+    else
+        hipLaunchKernelGGL((qring_kernel<NWALK, false>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, q->top,
+                           q->blocks, q->qinner, f->leaf_orig, sums, leaf_out, rows, f->p.num_cols, f->p.num_trees,
+                           f->depth, q->top_levels, q->top_stride, f->error_flag);
+}
+
+tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, const float *data, size_t rows,
+                          hipStream_t stream)
+{
+    tahoe_qstate *q = f->q;
+    const int nwalk = qring_walkers(f);
+    if (!q || nwalk == 0)
+        return fail(TAHOE_ERR_UNSUPPORTED,
+                    "QRING needs <= %d distinct thresholds per feature, num_cols <= 32767 and a 128-row u16 tile in LDS",
+                    kQMaxTable);
+    tahoe_status s = qring_reserve(f, rows);  // no-op unless this batch is larger than any before
+    if (s != TAHOE_OK) return s;
+    const size_t chunks = (rows + kQuantRowsPerBlock - 1) / kQuantRowsPerBlock;
+    const size_t qgrid = chunks * (size_t)f->p.num_cols;
+    if (qgrid > 0x7fffffffu) return fail(TAHOE_ERR_INVALID_ARG, "too many rows x cols for one launch");
+    hipLaunchKernelGGL(quantize_kernel, dim3((unsigned)qgrid), dim3(kQuantThreads), (size_t)std::max(q->max_table, 1) * 4, stream, data,
+                       q->tables, q->offsets, q->xq, rows, f->p.num_cols, f->p.missing);
+    TAHOE_HIP_TRY(hipGetLastError());
+    switch (nwalk) {
+        case 15: q_launch<15>(f, sums, leaf_out, rows, stream); break;
+        case 12: q_launch<12>(f, sums, leaf_out, rows, stream); break;
+        case 8: q_launch<8>(f, sums, leaf_out, rows, stream); break;
+        default: q_launch<4>(f, sums, leaf_out, rows, stream); break;
+    }
+    TAHOE_HIP_TRY(hipGetLastError());
+    return TAHOE_OK;
+}
+
+}  // namespace tahoe

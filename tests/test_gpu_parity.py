@@ -36,7 +36,8 @@ def run_case(env, nodes, T, D, C, data, strategies=None, missing=MISSING, **out)
     if strategies is None:
         strategies = [ta.STRATEGY_DIRECT] + ([ta.STRATEGY_ROWTILE] if info.lds_bytes_per_block > 0 else []) + (
             [ta.STRATEGY_TILEBLOCK] if info.tile_rows > 0 else []) + (
-            [ta.STRATEGY_TILERING] if info.ring_rows > 0 else []) + [ta.STRATEGY_AUTO]
+            [ta.STRATEGY_TILERING] if info.ring_rows > 0 else []) + (
+            [ta.STRATEGY_QRING] if info.qring_walkers > 0 else []) + [ta.STRATEGY_AUTO]
     for s in strategies:
         forest.set_strategy(s)
         leaf, sums = forest.predict_leaf_idx(x)
