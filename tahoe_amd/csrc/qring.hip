@@ -29,12 +29,13 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <type_traits>
 
 #include "forest_internal.h"
 
 struct tahoe_qstate {
     int top_levels = 0;
-    int max_table = 0;            // max n_f
+    int max_table = 0;            // floats of the largest per-feature search tree (2^p)
     bool have_mid = false;        // De - 2 > top_levels: heap of quantised nodes for the middle levels
     float *tables = nullptr;      // concatenated tab_f
     int *offsets = nullptr;       // [cols + 1]
@@ -44,6 +45,8 @@ struct tahoe_qstate {
     uint16_t *xq = nullptr;       // workspace: quantised tiles
     size_t xq_rows = 0;           // rows the workspace holds
     int top_stride = 0;           // u32 entries per tree in `top` (>= 4)
+    uint32_t *chunk_flags = nullptr;  // workspace: per kQuantRowsPerBlock rows, "a missing value was seen"
+    size_t n_chunk_flags = 0;
 };
 
 namespace tahoe {
@@ -68,23 +71,27 @@ __host__ __device__ __forceinline__ int qrow_pos(int r) { return ((r & 31) << 1)
 // the 64-byte lines of the row-major input are shared through L2.
 __global__ void __launch_bounds__(kQuantThreads) quantize_kernel(const float *__restrict__ data, const float *__restrict__ tables,
                                                        const int *__restrict__ offsets, uint16_t *__restrict__ xq,
-                                                       size_t rows, int cols, float missing)
+                                                       uint32_t *__restrict__ chunk_flags, size_t rows, int cols,
+                                                       float missing)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *tab = reinterpret_cast<float *>(smem);
     const int f = blockIdx.x % cols;
     const size_t chunk = blockIdx.x / cols;
+    // The feature's thresholds as a perfect binary search tree in level order (1-based, NaN padding):
+    // size = 2^p entries.  A probe sequence touches one entry per level, and a level is contiguous, so
+    // the 64 lanes of a probe spread over the LDS banks (a sorted array probed at power-of-two strides
+    // puts every lane in the same bank: 32-way conflicts, measured).
     const int base = offsets[f];
-    const int n = offsets[f + 1] - base;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) tab[i] = tables[base + i];
+    const int size = offsets[f + 1] - base;  // 2^p, p >= 0 (size 1 = no thresholds)
+    for (int i = threadIdx.x; i < size; i += blockDim.x) tab[i] = tables[base + i];
     __syncthreads();
-    int top_step = 1;
-    while (top_step * 2 <= n) top_step *= 2;  // largest power of two <= n (1 when n <= 1)
     const size_t r0 = chunk * kQuantRowsPerBlock;
     const size_t r1 = min(rows, r0 + (size_t)kQuantRowsPerBlock);
     // Four rows per thread and iteration: four independent load + search chains hide the LDS latency of
     // the ~15 dependent probes each search makes.
     constexpr int U = 4;
+    bool saw_missing = false;
     for (size_t rb = r0 + threadIdx.x; rb < r1; rb += (size_t)blockDim.x * U) {
         float x[U];
         int cnt[U];
@@ -92,25 +99,27 @@ __global__ void __launch_bounds__(kQuantThreads) quantize_kernel(const float *__
         for (int u = 0; u < U; ++u) {
             const size_t r = min(rb + (size_t)u * blockDim.x, r1 - 1);  // clamped: in bounds, result unused
             x[u] = data[r * (size_t)cols + f];
-            cnt[u] = 0;
+            cnt[u] = 1;
         }
-        for (int step = top_step; step >= 1; step >>= 1) {
+        // descend: k <- 2k + (tab[k] <= x); after p levels k - 2^p = #{thresholds <= x} (NaN x -> 0)
+        for (int lim = size; lim > 1; lim >>= 1) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int probe = cnt[u] + step;  // count of table entries <= x, branch-free; NaN -> 0
-                if (probe <= n && tab[probe - 1] <= x[u]) cnt[u] = probe;
-            }
+            for (int u = 0; u < U; ++u) cnt[u] = 2 * cnt[u] + (tab[cnt[u]] <= x[u] ? 1 : 0);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const size_t r = rb + (size_t)u * blockDim.x;
             if (r < r1) {
-                const uint32_t code = (fabsf(x[u] - missing) <= kMissingEps) ? kCodeMissing : (uint32_t)cnt[u];
+                const bool ms = fabsf(x[u] - missing) <= kMissingEps;
+                saw_missing |= ms;
+                const uint32_t code = ms ? kCodeMissing : (uint32_t)(cnt[u] - size);
                 xq[(r / kQRows) * ((size_t)cols * kQRows) + (size_t)f * kQRows + qrow_pos((int)(r % kQRows))] =
                     (uint16_t)code;
             }
         }
     }
+    // one atomic per wave at most: tells the walk kernel whether this row chunk needs the missing rule
+    if (__ballot(saw_missing) != 0 && (threadIdx.x & 63) == 0) atomicOr(&chunk_flags[chunk], 1u);
 }
 
 // Ring flags: relaxed workgroup-scope accesses (plain ds_read/ds_write that the compiler neither caches
@@ -127,16 +136,21 @@ __device__ __forceinline__ void lds_flag_store(uint32_t *p, uint32_t v)
 // The branch rule on codes: right <=> (missing ? !def_left : code(x) >= code(thr)).  Written on wave
 // masks: three v_cmp into SGPR pairs, three SALU ops, and the result is used directly as the lane
 // predicate of v_cndmask / v_addc (hipcc's ?: form materialises both booleans in VGPRs: 6 more VALU).
+// MS = false is the fast path for row chunks in which the quantise pass met no missing value (it
+// reports that per chunk): the rule is then the single compare.
+template <bool MS>
 __device__ __forceinline__ uint64_t q_right_mask(uint32_t xc, uint32_t node)
 {
     const uint64_t ge = __builtin_amdgcn_uicmp(xc, node & 0xFFFFu, 35 /* ICMP_UGE */);
+    if (!MS) return ge;
     const uint64_t ms = __builtin_amdgcn_uicmp(xc, kCodeMissing, 32 /* ICMP_EQ */);
     const uint64_t ndl = __builtin_amdgcn_sicmp((int)node, -1, 38 /* ICMP_SGT: bit 31 (def_left) clear */);
     return (ge & ~ms) | (ms & ndl);
 }
+template <bool MS>
 __device__ __forceinline__ bool q_go_right(uint32_t xc, uint32_t node)
 {
-    return __builtin_amdgcn_inverse_ballot_w64(q_right_mask(xc, node));
+    return __builtin_amdgcn_inverse_ballot_w64(q_right_mask<MS>(xc, node));
 }
 // i <- 2i + (lane's bit of mask): one v_addc with the mask as carry-in
 __device__ __forceinline__ uint32_t q_descend(uint32_t i, uint64_t right_mask)
@@ -167,7 +181,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
     qring_kernel(const uint16_t *__restrict__ xq, const uint32_t *__restrict__ top, const uint4 *__restrict__ blocks,
                  const uint32_t *__restrict__ qinner, const uint32_t *__restrict__ leaf_orig, float *__restrict__ sums,
                  uint32_t *__restrict__ leaf_out, size_t rows, int cols, int num_trees, int depth, int top_levels,
-                 int top_stride, int *__restrict__ error_flag)
+                 int top_stride, const uint32_t *__restrict__ chunk_flags, int *__restrict__ error_flag)
 {
     constexpr int K = kQRows / 64;  // two 64-row chains per walker lane
     constexpr int NT = (NWALK + 1) * 64;
@@ -263,111 +277,119 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
     }
     __syncthreads();  // the tile, the ring state and (own wave) the first top are in LDS
 
-    uint32_t pos[K];  // byte position of this lane's row inside a 256-byte feature column, per chain
-#pragma unroll
-    for (int k = 0; k < K; ++k) pos[k] = 2u * (uint32_t)qrow_pos(k * 64 + lane);
-    const size_t n_inner = ((size_t)1 << depth) - 1;
-    const uint32_t n_blocks = 1u << (depth - 2);
-    const uint32_t first_block_node = n_blocks - 1;
     bool dead = false;
-    // last two levels + leaf of tree t from its 32-byte blocks, then the hand-over to the consumer
-    auto finish = [&](int t, const uint4 (&na)[K], const uint4 (&nb)[K], const uint32_t (&bs)[K]) {
-        float v[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            // two dependent steps (the kernel is VALU-bound: this is ~half the instructions of evaluating
-            // both second-level nodes)
-            const bool c0 = q_go_right(q_xread(tile, na[k].x, pos[k]), na[k].x);
-            const uint32_t n1 = c0 ? na[k].z : na[k].y;
-            const bool c1 = q_go_right(q_xread(tile, n1, pos[k]), n1);
-            const uint32_t lo = c0 ? nb[k].z : nb[k].x, hi = c0 ? nb[k].w : nb[k].y;
-            v[k] = __uint_as_float(c1 ? hi : lo);
-            if (WRITE_LEAF) {
-                const size_t row = row0 + k * 64 + lane;
-                if (row < rows)
-                    leaf_out[row * (size_t)num_trees + t] =
-                        leaf_orig[(size_t)t * ((size_t)n_blocks * 4) + (size_t)bs[k] * 4 + 2 * (c0 ? 1 : 0) + (c1 ? 1 : 0)];
-            }
-        }
-        if (t >= kQRing) {  // ring entry still in use by tree t - kQRing?
-            int spins = 0;
-            while (lds_flag_load(consumed) < (uint32_t)(t - kQRing + 1)) {
-                if (++spins > kQSpinLimit) {
-                    dead = true;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-        }
-        const int e = t % kQRing;
-#pragma unroll
-        for (int k = 0; k < K; ++k) ring_vals[e * kQRows + k * 64 + lane] = v[k];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // values before the flag (in-order LDS)
-        if (lane == 0) lds_flag_store(&ring_ready[e], (uint32_t)(t + 1));
-    };
-    int t_p = -1;  // tree whose bottom blocks are in flight
-    uint4 na_p[K] = {}, nb_p[K] = {};
-    uint32_t bsel_p[K] = {};
-    for (int t = wave; t < num_trees && !dead; t += NWALK) {
-        const bool more = t + NWALK < num_trees;
-        if (more) prefetch_top(t + NWALK);
-        uint32_t i[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) i[k] = 1;
-        if (top_levels > 0) {
-            uint32_t node[K];
-#pragma unroll
-            for (int k = 0; k < K; ++k) node[k] = slot[1];
-            for (int l = 0; l < top_levels - 1; ++l) {
-                uint32_t xc[K];
-                uint2 pr[K];
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    xc[k] = q_xread(tile, node[k], pos[k]);
-                    pr[k] = *reinterpret_cast<const uint2 *>(&slot[2 * i[k]]);  // children 2i, 2i+1
-                }
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const uint64_t cm = q_right_mask(xc[k], node[k]);
-                    i[k] = q_descend(i[k], cm);
-                    node[k] = __builtin_amdgcn_inverse_ballot_w64(cm) ? pr[k].y : pr[k].x;
-                }
-            }
+    auto run = [&](auto ms_tag) {
+        constexpr bool MS = decltype(ms_tag)::value;
+        uint32_t pos[K];  // byte position of this lane's row inside a 256-byte feature column, per chain
+    #pragma unroll
+        for (int k = 0; k < K; ++k) pos[k] = 2u * (uint32_t)qrow_pos(k * 64 + lane);
+        const size_t n_inner = ((size_t)1 << depth) - 1;
+        const uint32_t n_blocks = 1u << (depth - 2);
+        const uint32_t first_block_node = n_blocks - 1;
+        // last two levels + leaf of tree t from its 32-byte blocks, then the hand-over to the consumer
+        auto finish = [&](int t, const uint4 (&na)[K], const uint4 (&nb)[K], const uint32_t (&bs)[K]) {
+            float v[K];
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                const uint32_t xc = q_xread(tile, node[k], pos[k]);
-                i[k] = q_descend(i[k], q_right_mask(xc, node[k]));
-            }
-        }
-        uint32_t bsel[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            uint32_t idx = i[k] - 1;  // 0-based heap index on level top_levels
-            if (top_levels < depth - 2) {  // deep trees only (De > 12): quantised heap nodes from global memory
-                const uint32_t *tree = qinner + (size_t)t * n_inner;
-                for (int l = top_levels; l < depth - 2; ++l) {
-                    const uint32_t n = tree[idx];
-                    const uint32_t xc = q_xread(tile, n, pos[k]);
-                    idx = 2u * idx + 1u + (q_go_right(xc, n) ? 1u : 0u);
+                // two dependent steps (the kernel is VALU-bound: this is ~half the instructions of evaluating
+                // both second-level nodes)
+                const bool c0 = q_go_right<MS>(q_xread(tile, na[k].x, pos[k]), na[k].x);
+                const uint32_t n1 = c0 ? na[k].z : na[k].y;
+                const bool c1 = q_go_right<MS>(q_xread(tile, n1, pos[k]), n1);
+                const uint32_t lo = c0 ? nb[k].z : nb[k].x, hi = c0 ? nb[k].w : nb[k].y;
+                v[k] = __uint_as_float(c1 ? hi : lo);
+                if (WRITE_LEAF) {
+                    const size_t row = row0 + k * 64 + lane;
+                    if (row < rows)
+                        leaf_out[row * (size_t)num_trees + t] =
+                            leaf_orig[(size_t)t * ((size_t)n_blocks * 4) + (size_t)bs[k] * 4 + 2 * (c0 ? 1 : 0) + (c1 ? 1 : 0)];
                 }
             }
-            bsel[k] = idx - first_block_node;
-        }
-        // ---- software pipeline: finish the PREVIOUS tree (its bottom-block gathers were issued one
-        // iteration ago and have been flying under this top walk), then issue this tree's gathers
-        // into the same registers ----
-        if (t_p >= 0) finish(t_p, na_p, nb_p, bsel_p);
-        t_p = t;
+            if (t >= kQRing) {  // ring entry still in use by tree t - kQRing?
+                int spins = 0;
+                while (lds_flag_load(consumed) < (uint32_t)(t - kQRing + 1)) {
+                    if (++spins > kQSpinLimit) {
+                        dead = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            const int e = t % kQRing;
+    #pragma unroll
+            for (int k = 0; k < K; ++k) ring_vals[e * kQRows + k * 64 + lane] = v[k];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // values before the flag (in-order LDS)
+            if (lane == 0) lds_flag_store(&ring_ready[e], (uint32_t)(t + 1));
+        };
+        int t_p = -1;  // tree whose bottom blocks are in flight
+        uint4 na_p[K] = {}, nb_p[K] = {};
+        uint32_t bsel_p[K] = {};
+        for (int t = wave; t < num_trees && !dead; t += NWALK) {
+            const bool more = t + NWALK < num_trees;
+            if (more) prefetch_top(t + NWALK);
+            uint32_t i[K];
+    #pragma unroll
+            for (int k = 0; k < K; ++k) i[k] = 1;
+            if (top_levels > 0) {
+                uint32_t node[K];
+    #pragma unroll
+                for (int k = 0; k < K; ++k) node[k] = slot[1];
+                for (int l = 0; l < top_levels - 1; ++l) {
+                    uint32_t xc[K];
+                    uint2 pr[K];
+    #pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        xc[k] = q_xread(tile, node[k], pos[k]);
+                        pr[k] = *reinterpret_cast<const uint2 *>(&slot[2 * i[k]]);  // children 2i, 2i+1
+                    }
+    #pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const uint64_t cm = q_right_mask<MS>(xc[k], node[k]);
+                        i[k] = q_descend(i[k], cm);
+                        node[k] = __builtin_amdgcn_inverse_ballot_w64(cm) ? pr[k].y : pr[k].x;
+                    }
+                }
+    #pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const uint32_t xc = q_xread(tile, node[k], pos[k]);
+                    i[k] = q_descend(i[k], q_right_mask<MS>(xc, node[k]));
+                }
+            }
+            uint32_t bsel[K];
+    #pragma unroll
+            for (int k = 0; k < K; ++k) {
+                uint32_t idx = i[k] - 1;  // 0-based heap index on level top_levels
+                if (top_levels < depth - 2) {  // deep trees only (De > 12): quantised heap nodes from global memory
+                    const uint32_t *tree = qinner + (size_t)t * n_inner;
+                    for (int l = top_levels; l < depth - 2; ++l) {
+                        const uint32_t n = tree[idx];
+                        const uint32_t xc = q_xread(tile, n, pos[k]);
+                        idx = 2u * idx + 1u + (q_go_right<MS>(xc, n) ? 1u : 0u);
+                    }
+                }
+                bsel[k] = idx - first_block_node;
+            }
+            // ---- software pipeline: finish the PREVIOUS tree (its bottom-block gathers were issued one
+            // iteration ago and have been flying under this top walk), then issue this tree's gathers
+            // into the same registers ----
+            if (t_p >= 0) finish(t_p, na_p, nb_p, bsel_p);
+            t_p = t;
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const uint4 *bp = blocks + ((size_t)t * n_blocks + bsel[k]) * 2;
-            na_p[k] = bp[0];  // node0, node1, node2, 0
-            nb_p[k] = bp[1];  // four leaf values
-            bsel_p[k] = bsel[k];
+            for (int k = 0; k < K; ++k) {
+                const uint4 *bp = blocks + ((size_t)t * n_blocks + bsel[k]) * 2;
+                na_p[k] = bp[0];  // node0, node1, node2, 0
+                nb_p[k] = bp[1];  // four leaf values
+                bsel_p[k] = bsel[k];
+            }
+            if (more) commit_top();  // this wave's reads of its slot are done (in-order LDS)
         }
-        if (more) commit_top();  // this wave's reads of its slot are done (in-order LDS)
-    }
-    if (t_p >= 0 && !dead) finish(t_p, na_p, nb_p, bsel_p);
+        if (t_p >= 0 && !dead) finish(t_p, na_p, nb_p, bsel_p);
+    };
+    // chunk_flags[c] != 0 <=> the quantise pass met a missing value in rows [c, c+1) * kQuantRowsPerBlock
+    if (chunk_flags[row0 / kQuantRowsPerBlock] != 0)
+        run(std::true_type{});
+    else
+        run(std::false_type{});
     if (dead && lane == 0) atomicOr(error_flag, 1);
 }
 
@@ -441,8 +463,34 @@ tahoe_status qring_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner,
         offsets[c + 1] = offsets[c] + (int)v.size();
     }
     if (max_table > kQMaxTable) return TAHOE_OK;  // unavailable: the float32 strategies serve this forest
-    std::vector<float> tables((size_t)offsets[cols]);
-    for (int c = 0; c < cols; ++c) std::copy(tab[c].begin(), tab[c].end(), tables.begin() + offsets[c]);
+    // device form of each table: perfect BST in level order, 1-based, 2^p entries, NaN padding (compares
+    // false, i.e. "greater than every x"); entry 0 unused
+    std::vector<float> tables;
+    int max_size = 1;
+    for (int c = 0; c < cols; ++c) {
+        const auto &v = tab[c];
+        int size = 1;
+        while (size - 1 < (int)v.size()) size *= 2;  // 2^p with 2^p - 1 >= n
+        max_size = std::max(max_size, size);
+        offsets[c] = (int)tables.size();
+        const size_t at = tables.size();
+        tables.resize(at + (size_t)size, std::nanf(""));
+        // in-order walk of the implicit tree assigns the sorted values
+        size_t next = 0;
+        std::vector<int> stack;
+        int k = 1;
+        while ((k < size) || !stack.empty()) {
+            while (k < size) {
+                stack.push_back(k);
+                k = 2 * k;
+            }
+            k = stack.back();
+            stack.pop_back();
+            if (next < v.size()) tables[at + (size_t)k] = v[next++];
+            k = 2 * k + 1;
+        }
+    }
+    offsets[cols] = (int)tables.size();
 
     // ---- node codes ----
     auto encode = [&](const InnerNode &n, bool real) -> uint32_t {
@@ -460,7 +508,7 @@ tahoe_status qring_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner,
     tahoe_qstate *q = new (std::nothrow) tahoe_qstate();
     if (!q) return fail(TAHOE_ERR_NO_MEMORY, "qring_build");
     f->q = q;
-    q->max_table = max_table;
+    q->max_table = max_size;  // LDS floats the quantise kernel needs
     const int De = f->depth;
     q->top_levels = f->top_levels;
     q->have_mid = De - 2 > q->top_levels;
@@ -509,9 +557,9 @@ tahoe_status qring_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner,
     if (qring_lds_for(f, 12) <= f->lds_limit && (e = q_allow<12>(qring_lds_for(f, 12))) != hipSuccess) return bad("attr12");
     if (qring_lds_for(f, 8) <= f->lds_limit && (e = q_allow<8>(qring_lds_for(f, 8))) != hipSuccess) return bad("attr8");
     if (qring_lds_for(f, 4) <= f->lds_limit && (e = q_allow<4>(qring_lds_for(f, 4))) != hipSuccess) return bad("attr4");
-    if (max_table * 4 > 64 * 1024 &&
+    if (max_size * 4 > 64 * 1024 &&
         (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&quantize_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, kQMaxTable * 4)) != hipSuccess)
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, max_size * 4)) != hipSuccess)
         return bad("attr(quantize)");
     return TAHOE_OK;
 }
@@ -521,7 +569,7 @@ void qring_destroy(tahoe_forest *f)
     tahoe_qstate *q = f->q;
     if (!q) return;
     for (void *p : {(void *)q->tables, (void *)q->offsets, (void *)q->top, (void *)q->blocks, (void *)q->qinner,
-                    (void *)q->xq})
+                    (void *)q->xq, (void *)q->chunk_flags})
         if (p) (void)hipFree(p);
     delete q;
     f->q = nullptr;
@@ -545,6 +593,9 @@ tahoe_status qring_reserve(tahoe_forest *f, size_t rows)
     TAHOE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&q->xq), bytes));
     q->xq_rows = tiles * kQRows;
     f->device_bytes += bytes;
+    if (q->chunk_flags) TAHOE_HIP_TRY(hipFree(q->chunk_flags));
+    q->n_chunk_flags = (q->xq_rows + kQuantRowsPerBlock - 1) / kQuantRowsPerBlock + 1;
+    TAHOE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&q->chunk_flags), q->n_chunk_flags * sizeof(uint32_t)));
     return TAHOE_OK;
 }
 
@@ -557,11 +608,11 @@ static void q_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, size_t ro
     if (leaf_out)
         hipLaunchKernelGGL((qring_kernel<NWALK, true>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, q->top,
                            q->blocks, q->qinner, f->leaf_orig, sums, leaf_out, rows, f->p.num_cols, f->p.num_trees,
-                           f->depth, q->top_levels, q->top_stride, f->error_flag);
+                           f->depth, q->top_levels, q->top_stride, q->chunk_flags, f->error_flag);
     else
         hipLaunchKernelGGL((qring_kernel<NWALK, false>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, q->top,
                            q->blocks, q->qinner, f->leaf_orig, sums, leaf_out, rows, f->p.num_cols, f->p.num_trees,
-                           f->depth, q->top_levels, q->top_stride, f->error_flag);
+                           f->depth, q->top_levels, q->top_stride, q->chunk_flags, f->error_flag);
 }
 
 tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, const float *data, size_t rows,
@@ -578,8 +629,9 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
     const size_t chunks = (rows + kQuantRowsPerBlock - 1) / kQuantRowsPerBlock;
     const size_t qgrid = chunks * (size_t)f->p.num_cols;
     if (qgrid > 0x7fffffffu) return fail(TAHOE_ERR_INVALID_ARG, "too many rows x cols for one launch");
+    TAHOE_HIP_TRY(hipMemsetAsync(q->chunk_flags, 0, q->n_chunk_flags * sizeof(uint32_t), stream));
     hipLaunchKernelGGL(quantize_kernel, dim3((unsigned)qgrid), dim3(kQuantThreads), (size_t)std::max(q->max_table, 1) * 4, stream, data,
-                       q->tables, q->offsets, q->xq, rows, f->p.num_cols, f->p.missing);
+                       q->tables, q->offsets, q->xq, q->chunk_flags, rows, f->p.num_cols, f->p.missing);
     TAHOE_HIP_TRY(hipGetLastError());
     switch (nwalk) {
         case 15: q_launch<15>(f, sums, leaf_out, rows, stream); break;
