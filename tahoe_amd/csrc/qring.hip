@@ -47,6 +47,7 @@ struct tahoe_qstate {
     int top_stride = 0;           // u32 entries per tree in `top` (>= 4)
     uint32_t *chunk_flags = nullptr;  // workspace: per kQuantRowsPerBlock rows, "a missing value was seen"
     size_t n_chunk_flags = 0;
+    int pair_lds_floats = 0;      // LDS floats of quantize_pair_kernel; 0 = odd num_cols, single-feature form
 };
 
 namespace tahoe {
@@ -66,59 +67,169 @@ constexpr uint32_t kCodeMissing = 0xFFFFu;
 __host__ __device__ __forceinline__ int qrow_pos(int r) { return ((r & 31) << 1) | ((r >> 5) & 1) | ((r >> 6) << 6); }
 
 // ------------------------------------------------------------------------------------------------
-// (1) float32 rows -> u16 codes.  One workgroup = one feature x kQuantRowsPerBlock rows; the
-// feature's table sits in LDS; consecutive workgroups take consecutive features of the same rows, so
-// the 64-byte lines of the row-major input are shared through L2.
+// (1) float32 rows -> u16 codes.  One workgroup = F adjacent features x kQuantRowsPerBlock rows, the F
+// search trees in LDS (stride `tab_stride` floats).  A thread reads the F values of a row with one
+// F*4-byte load: the row-major input is fetched in 64-byte lines of 16 features, and a workgroup uses
+// F*4 bytes of each line it pulls through L2 -> L1, so F = 2 halves and F = 4 quarters that traffic
+// (the kernel was bound by it at F = 1: 16 GB of line traffic for a 1 GB batch).
+template <int F>
+struct QVec;
+template <>
+struct QVec<1> { using T = float; };
+template <>
+struct QVec<2> { using T = float2; };
+template <>
+struct QVec<4> { using T = float4; };
+__device__ __forceinline__ float qv_get(float v, int) { return v; }
+__device__ __forceinline__ float qv_get(float2 v, int j) { return j == 0 ? v.x : v.y; }
+__device__ __forceinline__ float qv_get(float4 v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
+
+template <int F>
 __global__ void __launch_bounds__(kQuantThreads) quantize_kernel(const float *__restrict__ data, const float *__restrict__ tables,
-                                                       const int *__restrict__ offsets, uint16_t *__restrict__ xq,
-                                                       uint32_t *__restrict__ chunk_flags, size_t rows, int cols,
-                                                       float missing)
+                                                                 const int *__restrict__ offsets, uint16_t *__restrict__ xq,
+                                                                 uint32_t *__restrict__ chunk_flags, size_t rows, int cols,
+                                                                 float missing, int tab_stride)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *tab = reinterpret_cast<float *>(smem);
-    const int f = blockIdx.x % cols;
-    const size_t chunk = blockIdx.x / cols;
-    // The feature's thresholds as a perfect binary search tree in level order (1-based, NaN padding):
-    // size = 2^p entries.  A probe sequence touches one entry per level, and a level is contiguous, so
-    // the 64 lanes of a probe spread over the LDS banks (a sorted array probed at power-of-two strides
-    // puts every lane in the same bank: 32-way conflicts, measured).
-    const int base = offsets[f];
-    const int size = offsets[f + 1] - base;  // 2^p, p >= 0 (size 1 = no thresholds)
-    for (int i = threadIdx.x; i < size; i += blockDim.x) tab[i] = tables[base + i];
+    // Workgroups are dealt round-robin over the 8 XCDs (private L2s): give every XCD a contiguous range of
+    // (chunk, feature group) pairs, so the workgroups that re-read a line sit behind the same L2 (placement
+    // is a speed matter only; any mapping is correct).
+    const unsigned nblk = gridDim.x;
+    const unsigned vid = (nblk % 8u == 0u) ? (blockIdx.x % 8u) * (nblk / 8u) + blockIdx.x / 8u : blockIdx.x;
+    const int groups = cols / F;
+    const int f0 = (int)(vid % groups) * F;
+    const size_t chunk = vid / groups;
+    // Each feature's thresholds as a perfect binary search tree in level order (1-based, NaN padding),
+    // size = 2^p entries.  A probe sequence touches one entry per level and a level is contiguous, so the 64
+    // lanes of a probe spread over the LDS banks (a sorted array probed at power-of-two strides puts every
+    // lane in the same bank: 32-way conflicts, measured).
+    int size[F];
+#pragma unroll
+    for (int j = 0; j < F; ++j) {
+        const int base = offsets[f0 + j];
+        size[j] = offsets[f0 + j + 1] - base;  // 2^p, p >= 0 (size 1 = no thresholds)
+        for (int i = threadIdx.x; i < size[j]; i += blockDim.x) tab[j * tab_stride + i] = tables[base + i];
+    }
     __syncthreads();
     const size_t r0 = chunk * kQuantRowsPerBlock;
     const size_t r1 = min(rows, r0 + (size_t)kQuantRowsPerBlock);
-    // Four rows per thread and iteration: four independent load + search chains hide the LDS latency of
-    // the ~15 dependent probes each search makes.
-    constexpr int U = 4;
+    constexpr int U = (F == 1) ? 4 : 2;  // rows per thread and iteration: U * F independent search chains
+    using V = typename QVec<F>::T;
     bool saw_missing = false;
     for (size_t rb = r0 + threadIdx.x; rb < r1; rb += (size_t)blockDim.x * U) {
-        float x[U];
-        int cnt[U];
+        V xv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const size_t r = min(rb + (size_t)u * blockDim.x, r1 - 1);  // clamped: in bounds, result unused
-            x[u] = data[r * (size_t)cols + f];
-            cnt[u] = 1;
-        }
-        // descend: k <- 2k + (tab[k] <= x); after p levels k - 2^p = #{thresholds <= x} (NaN x -> 0)
-        for (int lim = size; lim > 1; lim >>= 1) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) cnt[u] = 2 * cnt[u] + (tab[cnt[u]] <= x[u] ? 1 : 0);
+            xv[u] = *reinterpret_cast<const V *>(data + r * (size_t)cols + f0);
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const size_t r = rb + (size_t)u * blockDim.x;
-            if (r < r1) {
-                const bool ms = fabsf(x[u] - missing) <= kMissingEps;
-                saw_missing |= ms;
-                const uint32_t code = ms ? kCodeMissing : (uint32_t)(cnt[u] - size);
-                xq[(r / kQRows) * ((size_t)cols * kQRows) + (size_t)f * kQRows + qrow_pos((int)(r % kQRows))] =
-                    (uint16_t)code;
+        for (int j = 0; j < F; ++j) {
+            const float *tj = tab + j * tab_stride;
+            float x[U];
+            int cnt[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                x[u] = qv_get(xv[u], j);
+                cnt[u] = 1;
+            }
+            // descend: k <- 2k + (tab[k] <= x); after p levels k - 2^p = #{thresholds <= x} (NaN x -> 0)
+            for (int lim = size[j]; lim > 1; lim >>= 1) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) cnt[u] = 2 * cnt[u] + (tj[cnt[u]] <= x[u] ? 1 : 0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const size_t r = rb + (size_t)u * blockDim.x;
+                if (r < r1) {
+                    const bool ms = fabsf(x[u] - missing) <= kMissingEps;
+                    saw_missing |= ms;
+                    const uint32_t code = ms ? kCodeMissing : (uint32_t)(cnt[u] - size[j]);
+                    xq[(r / kQRows) * ((size_t)cols * kQRows) + (size_t)(f0 + j) * kQRows + qrow_pos((int)(r % kQRows))] =
+                        (uint16_t)code;
+                }
             }
         }
     }
     // one atomic per wave at most: tells the walk kernel whether this row chunk needs the missing rule
+    if (__ballot(saw_missing) != 0 && (threadIdx.x & 63) == 0) atomicOr(&chunk_flags[chunk], 1u);
+}
+
+// Pair form used when num_cols is even: one workgroup = features (f0, f0+1) x kQuantRowsPerBlock rows, float2
+// loads.  When both search trees fit the LDS budget they are resident together (one pass); a pair with an
+// oversized tree is done in two passes with one tree resident at a time, so a few large features do not
+// force the whole launch down to one feature per workgroup.
+constexpr int kQuantPairThreads = 1024;
+__global__ void __launch_bounds__(kQuantPairThreads)
+    quantize_pair_kernel(const float *__restrict__ data, const float *__restrict__ tables, const int *__restrict__ offsets,
+                         uint16_t *__restrict__ xq, uint32_t *__restrict__ chunk_flags, size_t rows, int cols, float missing,
+                         int lds_floats)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *tab = reinterpret_cast<float *>(smem);
+    const unsigned nblk = gridDim.x;
+    const unsigned vid = (nblk % 8u == 0u) ? (blockIdx.x % 8u) * (nblk / 8u) + blockIdx.x / 8u : blockIdx.x;  // XCD-contiguous
+    const int groups = cols / 2;
+    const int f0 = (int)(vid % groups) * 2;
+    const size_t chunk = vid / groups;
+    const int base0 = offsets[f0], base1 = offsets[f0 + 1];
+    const int size0 = base1 - base0, size1 = offsets[f0 + 2] - base1;
+    const bool together = size0 + size1 <= lds_floats;
+    const size_t r0 = chunk * kQuantRowsPerBlock;
+    const size_t r1 = min(rows, r0 + (size_t)kQuantRowsPerBlock);
+    constexpr int U = 2;
+    bool saw_missing = false;
+    for (int pass = 0; pass < (together ? 1 : 2); ++pass) {
+        if (pass) __syncthreads();  // everyone is done reading the first tree
+        const bool do0 = together || pass == 0, do1 = together || pass == 1;
+        const float *t0 = tab;
+        const float *t1 = together ? tab + size0 : tab;
+        if (do0)
+            for (int i = threadIdx.x; i < size0; i += blockDim.x) tab[i] = tables[base0 + i];
+        if (do1)
+            for (int i = threadIdx.x; i < size1; i += blockDim.x) tab[(together ? size0 : 0) + i] = tables[base1 + i];
+        __syncthreads();
+        for (size_t rb = r0 + threadIdx.x; rb < r1; rb += (size_t)blockDim.x * U) {
+            float2 xv[U];
+            int c0[U], c1[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const size_t r = min(rb + (size_t)u * blockDim.x, r1 - 1);  // clamped: in bounds, result unused
+                xv[u] = *reinterpret_cast<const float2 *>(data + r * (size_t)cols + f0);
+                c0[u] = 1;
+                c1[u] = 1;
+            }
+            // descend both trees: k <- 2k + (tab[k] <= x); k - 2^p = #{thresholds <= x} (NaN x -> 0)
+            if (do0)
+                for (int lim = size0; lim > 1; lim >>= 1) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) c0[u] = 2 * c0[u] + (t0[c0[u]] <= xv[u].x ? 1 : 0);
+                }
+            if (do1)
+                for (int lim = size1; lim > 1; lim >>= 1) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) c1[u] = 2 * c1[u] + (t1[c1[u]] <= xv[u].y ? 1 : 0);
+                }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const size_t r = rb + (size_t)u * blockDim.x;
+                if (r < r1) {
+                    uint16_t *dst = xq + (r / kQRows) * ((size_t)cols * kQRows) + (size_t)f0 * kQRows + qrow_pos((int)(r % kQRows));
+                    if (do0) {
+                        const bool ms = fabsf(xv[u].x - missing) <= kMissingEps;
+                        saw_missing |= ms;
+                        dst[0] = (uint16_t)(ms ? kCodeMissing : (uint32_t)(c0[u] - size0));
+                    }
+                    if (do1) {
+                        const bool ms = fabsf(xv[u].y - missing) <= kMissingEps;
+                        saw_missing |= ms;
+                        dst[kQRows] = (uint16_t)(ms ? kCodeMissing : (uint32_t)(c1[u] - size1));
+                    }
+                }
+            }
+        }
+    }
     if (__ballot(saw_missing) != 0 && (threadIdx.x & 63) == 0) atomicOr(&chunk_flags[chunk], 1u);
 }
 
@@ -557,8 +668,23 @@ tahoe_status qring_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner,
     if (qring_lds_for(f, 12) <= f->lds_limit && (e = q_allow<12>(qring_lds_for(f, 12))) != hipSuccess) return bad("attr12");
     if (qring_lds_for(f, 8) <= f->lds_limit && (e = q_allow<8>(qring_lds_for(f, 8))) != hipSuccess) return bad("attr8");
     if (qring_lds_for(f, 4) <= f->lds_limit && (e = q_allow<4>(qring_lds_for(f, 4))) != hipSuccess) return bad("attr4");
+    // quantise kernel form: feature pairs with both trees resident when they fit, else one feature per WG
+    q->pair_lds_floats = 0;
+    if (cols % 2 == 0) {
+        const int budget = 36 * 1024;  // floats: 144 KiB of LDS
+        int need = 0;
+        for (int c = 0; c < cols; c += 2) {
+            const int s0 = offsets[c + 1] - offsets[c], s1 = offsets[c + 2] - offsets[c + 1];
+            need = std::max(need, s0 + s1 <= budget ? s0 + s1 : std::max(s0, s1));
+        }
+        q->pair_lds_floats = std::max(need, 1);
+        if (q->pair_lds_floats * 4 > 64 * 1024 &&
+            (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&quantize_pair_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, q->pair_lds_floats * 4)) != hipSuccess)
+            return bad("attr(quantize_pair)");
+    }
     if (max_size * 4 > 64 * 1024 &&
-        (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&quantize_kernel),
+        (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&quantize_kernel<1>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, max_size * 4)) != hipSuccess)
         return bad("attr(quantize)");
     return TAHOE_OK;
@@ -627,11 +753,18 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
     tahoe_status s = qring_reserve(f, rows);  // no-op unless this batch is larger than any before
     if (s != TAHOE_OK) return s;
     const size_t chunks = (rows + kQuantRowsPerBlock - 1) / kQuantRowsPerBlock;
-    const size_t qgrid = chunks * (size_t)f->p.num_cols;
-    if (qgrid > 0x7fffffffu) return fail(TAHOE_ERR_INVALID_ARG, "too many rows x cols for one launch");
     TAHOE_HIP_TRY(hipMemsetAsync(q->chunk_flags, 0, q->n_chunk_flags * sizeof(uint32_t), stream));
-    hipLaunchKernelGGL(quantize_kernel, dim3((unsigned)qgrid), dim3(kQuantThreads), (size_t)std::max(q->max_table, 1) * 4, stream, data,
-                       q->tables, q->offsets, q->xq, q->chunk_flags, rows, f->p.num_cols, f->p.missing);
+    const bool pair_ok = q->pair_lds_floats > 0 && (reinterpret_cast<uintptr_t>(data) % 8) == 0;  // float2 loads
+    const size_t qgrid = chunks * (size_t)(pair_ok ? f->p.num_cols / 2 : f->p.num_cols);
+    if (qgrid > 0x7fffffffu) return fail(TAHOE_ERR_INVALID_ARG, "too many rows x cols for one launch");
+    if (pair_ok)
+        hipLaunchKernelGGL(quantize_pair_kernel, dim3((unsigned)qgrid), dim3(kQuantPairThreads),
+                           (size_t)q->pair_lds_floats * 4, stream, data, q->tables, q->offsets, q->xq, q->chunk_flags, rows,
+                           f->p.num_cols, f->p.missing, q->pair_lds_floats);
+    else
+        hipLaunchKernelGGL(quantize_kernel<1>, dim3((unsigned)qgrid), dim3(kQuantThreads), (size_t)std::max(q->max_table, 1) * 4,
+                           stream, data, q->tables, q->offsets, q->xq, q->chunk_flags, rows, f->p.num_cols, f->p.missing,
+                           std::max(q->max_table, 1));
     TAHOE_HIP_TRY(hipGetLastError());
     switch (nwalk) {
         case 15: q_launch<15>(f, sums, leaf_out, rows, stream); break;
