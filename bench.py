@@ -110,6 +110,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     kernel_ms = forest.kernel_times_ms()
+    prepass_ms = forest.prepass_times_ms()
     forest.set_profiling(0)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -124,11 +125,27 @@ def main():
     b_alg = algorithmic_bytes_per_sample(my_T, D, C, info.bits_bytes) * R
     k_ms = float(np.mean(kernel_ms)) if len(kernel_ms) else float("nan")
     achieved = b_alg / (k_ms * 1e-3) / 1e9
+    # HBM traffic per launch: PMC counters cannot be read from inside this process; the committed summary of
+    # the separate rocprofv3 --pmc passes (tools/pmc.sh, same command, K3 only) supplies it.
+    traffic = None
+    strategy_name = ta.STRATEGY_NAMES.get(forest.get_strategy(R), "?")
+    if (T, D, C, R) == (1000, 12, 256, 1_000_000) and world == 1:
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01", "hbm_traffic.json")) as fh:
+                entry = json.load(fh)["strategies"].get(strategy_name)
+            if entry:
+                traffic = int(sum((k["FETCH_SIZE_KB"] or 0) + (k["WRITE_SIZE_KB"] or 0) for k in entry.values()) * 1024)
+        except (OSError, KeyError, ValueError):
+            traffic = None
     roofline = {
-        "bound": "hbm", "kernel": ta.STRATEGY_NAMES.get(forest.get_strategy(R), "?") + "_kernel",
+        "bound": "hbm", "kernel": strategy_name + "_kernel",
         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+        "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+        "traffic_unit": "bytes per launch (FETCH_SIZE+WRITE_SIZE, raw; profiles/r01/hbm_traffic.json)",
         "kernel_ms_avg": round(k_ms, 4), "kernel_ms_min": round(float(np.min(kernel_ms)), 4) if len(kernel_ms) else None,
+        "prepass_kernel_ms_avg": round(float(np.mean(prepass_ms)), 4) if len(prepass_ms) else 0.0,
+        "frac_incl_prepass": round(b_alg / ((k_ms + (float(np.mean(prepass_ms)) if len(prepass_ms) else 0.0)) * 1e-3) / 1e9
+                                   / HBM_PEAK_GBPS, 4),
         "algorithmic_bytes_per_launch": b_alg,
         "compulsory_frac": round(((R * C * 4 + my_T * n_per_tree * (4 + info.bits_bytes) + R * 4) / (k_ms * 1e-3) / 1e9)
                                  / HBM_PEAK_GBPS, 5),

@@ -168,10 +168,13 @@ typedef struct {
 tahoe_status tahoe_forest_get_info(const tahoe_forest *f, tahoe_forest_info *info);
 
 /* Kernel timing with hipEvents on the stream the kernel runs on.  set_profiling(f, n) arms up to n
- * launches (0 disarms): each following predict brackets its traversal kernel with an event pair.
+ * launches (0 disarms): each following predict brackets its traversal kernel with an event pair (a pre-pass kernel, if
+ * the strategy has one, is timed apart: tahoe_forest_prepass_times).
  * kernel_times waits for the recorded launches and returns their durations in milliseconds. */
 tahoe_status tahoe_forest_set_profiling(tahoe_forest *f, int max_launches);
 tahoe_status tahoe_forest_kernel_times(tahoe_forest *f, float *ms_out, int capacity, int *count);
+/* Durations of the pre-pass kernel of the same launches (QRING's quantise kernel; 0 for the others). */
+tahoe_status tahoe_forest_prepass_times(tahoe_forest *f, float *ms_out, int capacity, int *count);
 
 /* ---- file formats (BaseTahoeTest.h:267-402): one value per line ---- */
 /* model: num_trees, levels(=depth+1), then per tree, per node in heap order: fid, value,

@@ -120,6 +120,7 @@ _PROTOS = {
     "tahoe_forest_get_info": (_i, [_vp, C.POINTER(ForestInfo)]),
     "tahoe_forest_set_profiling": (_i, [_vp, _i]),
     "tahoe_forest_kernel_times": (_i, [_vp, _vp, _i, C.POINTER(_i)]),
+    "tahoe_forest_prepass_times": (_i, [_vp, _vp, _i, C.POINTER(_i)]),
     "tahoe_load_model": (_i, [C.c_char_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_vp)]),
     "tahoe_load_data": (_i, [C.c_char_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_f), C.POINTER(_vp)]),
     "tahoe_write_model": (_i, [C.c_char_p, _i, _i, _vp]),
@@ -322,6 +323,14 @@ class Forest:
         n = _i()
         _check(lib.tahoe_forest_kernel_times(self._h, out.ctypes.data, capacity, C.byref(n)),
                "tahoe_forest_kernel_times")
+        return out[: n.value].copy()
+
+    def prepass_times_ms(self, capacity: int = 4096) -> np.ndarray:
+        """Durations (ms) of the pre-pass kernel (QRING's quantise kernel) of the same launches."""
+        out = np.empty(capacity, dtype=np.float32)
+        n = _i()
+        _check(lib.tahoe_forest_prepass_times(self._h, out.ctypes.data, capacity, C.byref(n)),
+               "tahoe_forest_prepass_times")
         return out[: n.value].copy()
 
 

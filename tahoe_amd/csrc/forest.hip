@@ -752,12 +752,14 @@ static tahoe_status launch_traversal(tahoe_forest *f, float *sums, uint32_t *lea
     if ((rows + 63) / 64 > 0x7fffffffu) return fail(TAHOE_ERR_INVALID_ARG, "too many rows for one launch: %zu", rows);
     const bool timed = f->profiling && f->prof_count < f->ev_start.size();
     if (timed) TAHOE_HIP_TRY(hipEventRecord(f->ev_start[f->prof_count], stream));
+    bool mid_recorded = false;
     const int vec4_ok = (f->p.num_cols % 4 == 0) && ((reinterpret_cast<uintptr_t>(data) & 15u) == 0);
     if (f->p.num_trees == 0) {
         // Nothing to walk: sums are zero (an empty j-loop in predict_on_cpu).
         if (sums) TAHOE_HIP_TRY(hipMemsetAsync(sums, 0, rows * sizeof(float), stream));
     } else if (strategy == TAHOE_STRATEGY_QRING) {
-        const tahoe_status qs = qring_launch(f, sums, leaf_out, data, rows, stream);
+        const tahoe_status qs = qring_launch(f, sums, leaf_out, data, rows, stream, timed ? f->ev_mid[f->prof_count] : nullptr);
+        mid_recorded = timed;
         if (qs != TAHOE_OK) return qs;
     } else if (strategy == TAHOE_STRATEGY_TILERING) {
         const int tr = tilering_rows(f);
@@ -809,6 +811,8 @@ static tahoe_status launch_traversal(tahoe_forest *f, float *sums, uint32_t *lea
         return fail(TAHOE_ERR_INVALID_ARG, "unknown strategy %d", strategy);
     }
     if (timed) {
+        // strategies without a pre-pass: mid = start (pre-pass time 0)
+        if (!mid_recorded) TAHOE_HIP_TRY(hipEventRecord(f->ev_mid[f->prof_count], stream));
         TAHOE_HIP_TRY(hipEventRecord(f->ev_stop[f->prof_count], stream));
         ++f->prof_count;
     }
@@ -1062,6 +1066,7 @@ void tahoe_forest_destroy(tahoe_forest *f)
     if (f->error_flag) (void)hipFree(f->error_flag);
     qring_destroy(f);
     for (hipEvent_t e : f->ev_start) (void)hipEventDestroy(e);
+    for (hipEvent_t e : f->ev_mid) (void)hipEventDestroy(e);
     for (hipEvent_t e : f->ev_stop) (void)hipEventDestroy(e);
     delete f;
 }
@@ -1175,7 +1180,15 @@ tahoe_status tahoe_forest_set_profiling(tahoe_forest *f, int max_launches)
             (void)hipEventDestroy(a);
             return fail(TAHOE_ERR_HIP, "hipEventCreate failed: %s", hipGetErrorString(e));
         }
+        hipEvent_t m;
+        e = hipEventCreate(&m);
+        if (e != hipSuccess) {
+            (void)hipEventDestroy(a);
+            (void)hipEventDestroy(b);
+            return fail(TAHOE_ERR_HIP, "hipEventCreate failed: %s", hipGetErrorString(e));
+        }
         f->ev_start.push_back(a);
+        f->ev_mid.push_back(m);
         f->ev_stop.push_back(b);
     }
     f->profiling = max_launches > 0;
@@ -1189,7 +1202,19 @@ tahoe_status tahoe_forest_kernel_times(tahoe_forest *f, float *ms_out, int capac
     const int n = (int)std::min<size_t>(f->prof_count, (size_t)std::max(capacity, 0));
     for (int i = 0; i < n; ++i) {
         TAHOE_HIP_TRY(hipEventSynchronize(f->ev_stop[i]));
-        TAHOE_HIP_TRY(hipEventElapsedTime(&ms_out[i], f->ev_start[i], f->ev_stop[i]));
+        TAHOE_HIP_TRY(hipEventElapsedTime(&ms_out[i], f->ev_mid[i], f->ev_stop[i]));
+    }
+    *count = n;
+    return TAHOE_OK;
+}
+
+tahoe_status tahoe_forest_prepass_times(tahoe_forest *f, float *ms_out, int capacity, int *count)
+{
+    if (!f || !count || (capacity > 0 && !ms_out)) return fail(TAHOE_ERR_INVALID_ARG, "null argument");
+    const int n = (int)std::min<size_t>(f->prof_count, (size_t)std::max(capacity, 0));
+    for (int i = 0; i < n; ++i) {
+        TAHOE_HIP_TRY(hipEventSynchronize(f->ev_mid[i]));
+        TAHOE_HIP_TRY(hipEventElapsedTime(&ms_out[i], f->ev_start[i], f->ev_mid[i]));
     }
     *count = n;
     return TAHOE_OK;

@@ -65,7 +65,7 @@ struct tahoe_forest {
     size_t device_bytes = 0;
     // Profiling: one hipEvent pair per traversal launch, read back after the stream has drained.
     bool profiling = false;
-    std::vector<hipEvent_t> ev_start, ev_stop;
+    std::vector<hipEvent_t> ev_start, ev_mid, ev_stop;  // mid: between a pre-pass kernel and the walk kernel
     size_t prof_count = 0;  // launches recorded since profiling was (re-)enabled
 };
 
@@ -78,8 +78,9 @@ tahoe_status qring_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner,
 void qring_destroy(tahoe_forest *f);
 int qring_walkers(const tahoe_forest *f);  // walker waves the kernel would use; 0 = strategy unavailable
 long long qring_lds_bytes(const tahoe_forest *f);
+// mid_event (optional) is recorded between the quantise kernel and the walk kernel
 tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, const float *data, size_t rows,
-                          hipStream_t stream);
+                          hipStream_t stream, hipEvent_t mid_event);
 tahoe_status qring_reserve(tahoe_forest *f, size_t rows);
 
 }  // namespace tahoe

@@ -742,7 +742,7 @@ static void q_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, size_t ro
 }
 
 tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, const float *data, size_t rows,
-                          hipStream_t stream)
+                          hipStream_t stream, hipEvent_t mid_event)
 {
     tahoe_qstate *q = f->q;
     const int nwalk = qring_walkers(f);
@@ -766,6 +766,7 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
                            stream, data, q->tables, q->offsets, q->xq, q->chunk_flags, rows, f->p.num_cols, f->p.missing,
                            std::max(q->max_table, 1));
     TAHOE_HIP_TRY(hipGetLastError());
+    if (mid_event) TAHOE_HIP_TRY(hipEventRecord(mid_event, stream));
     switch (nwalk) {
         case 15: q_launch<15>(f, sums, leaf_out, rows, stream); break;
         case 12: q_launch<12>(f, sums, leaf_out, rows, stream); break;

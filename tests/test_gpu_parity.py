@@ -250,3 +250,61 @@ def test_k3_full_size_properties(env):
     # (4) a ragged batch (not a multiple of the 64-row tile) matches the prefix of the full batch
     r_sums = forest.predict_raw(x[: 100_003].contiguous()).cpu().numpy()
     assert np.array_equal(bits(r_sums), bits(got[:100_003]))
+
+
+# ---- the rank-quantised path (QRING): exactness at the edges of the float order ----
+
+def test_quantised_threshold_edge_values(env):
+    """Thresholds and features drawn from {+-0, +-inf, NaN, denormals, duplicates, neighbours in float order};
+    the missing sentinel is itself one of the thresholds.  Codes must reproduce x >= thr for every pair."""
+    ta, oracle, torch = env
+    rng = np.random.default_rng(3)
+    T, D, C, R = 24, 6, 6, 1500
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 1.17549435e-38, 1.0, np.nextafter(np.float32(1), np.float32(2)),
+                        np.nextafter(np.float32(1), np.float32(0)), -1.0, 0.5, 0.5, 0.5, 3.4028235e38, -3.4028235e38, 0.25],
+                       dtype=np.float32)
+    nodes = ta.synth_forest(T, D, C, seed=31, leaf_prob=0.05)
+    inner = (nodes["bits"].view(np.uint32) >> 31) == 0
+    nodes["val"][inner] = special[rng.integers(0, special.size, size=int(inner.sum()))]
+    data = special[rng.integers(0, special.size, size=(R, C))]
+    info_missing = 0.25  # a threshold value that is also the missing sentinel
+    want, want_leaf = run_case(env, nodes, T, D, C, data, missing=info_missing)
+    f = ta.Forest(nodes, T, D, C, missing=info_missing)
+    assert f.info().qring_walkers > 0 and f.get_strategy(R) == ta.STRATEGY_QRING
+
+
+def test_qring_unavailable_with_too_many_thresholds(env):
+    """More than 32767 distinct thresholds on one feature: the quantised strategy steps aside, AUTO falls back
+    to a float32 strategy, results unchanged."""
+    ta, oracle, torch = env
+    T, D, C, R = 3, 15, 1, 300  # 3 x 32767 inner nodes, all on feature 0, all distinct
+    nodes = ta.synth_forest(T, D, C, seed=41)
+    data = ta.synth_data(R, C, seed=42, missing_prob=0.05, missing=MISSING)
+    f = ta.Forest(nodes, T, D, C, missing=MISSING)
+    assert f.info().qring_walkers == 0
+    with pytest.raises(ta.TahoeError) as e:
+        f.set_strategy(ta.STRATEGY_QRING)
+    assert e.value.status == 7
+    assert f.get_strategy(R) in (ta.STRATEGY_TILERING, ta.STRATEGY_TILEBLOCK, ta.STRATEGY_ROWTILE)
+    run_case(env, nodes, T, D, C, data)
+
+
+def test_qring_missing_only_in_a_late_chunk_and_workspace_growth(env):
+    """Rows are quantised in chunks of 32768; a chunk without missing values takes the single-compare fast
+    path.  Missing values only in the third chunk exercise both paths in one launch; batches of growing and
+    shrinking size exercise the grow-only workspace."""
+    ta, oracle, torch = env
+    T, D, C, R = 10, 7, 12, 80_000
+    nodes = ta.synth_forest(T, D, C, seed=51, leaf_prob=0.05)
+    data = ta.synth_data(R, C, seed=52)
+    late = ta.synth_data(R - 70_000, C, seed=53, missing_prob=0.2, missing=MISSING, nan_prob=0.05)
+    data[70_000:] = late
+    f = ta.Forest(nodes, T, D, C, missing=MISSING)
+    f.set_strategy(ta.STRATEGY_QRING)
+    for n in (1000, R, 129, 40_000):
+        x = torch.from_numpy(data[R - n:].copy()).cuda()
+        want, want_leaf = oracle.predict(nodes, T, D, data[R - n:], MISSING, want_leaf=True, threads=8)
+        leaf, sums = f.predict_leaf_idx(x)
+        f.check()
+        assert np.array_equal(bits(leaf.cpu().numpy()), want_leaf), n
+        assert np.array_equal(bits(sums.cpu().numpy()), bits(want)), n
