@@ -271,17 +271,16 @@ __device__ __forceinline__ uint32_t q_descend(uint32_t i, uint64_t right_mask)
     asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(r), "=&s"(carry_out) : "v"(i), "s"(right_mask));
     return r;
 }
-// byte offset of the u16 code of feature fid(node) for the row at byte position pos2 of a column:
-// (fid << 8) | pos2, two VALU (shift, and-or) instead of the three hipcc emits for the C expression
-__device__ __forceinline__ uint32_t q_xoff(uint32_t node, uint32_t pos2)
+// The u16 code of feature fid(node) for this lane's row.  `posb` = LDS byte address of the row's slot in
+// feature column 0 (tile base + position); a column is 256 bytes.  The address is formed as an LDS
+// (address-space 3) integer, fid * 256 + posb: v_bfe + v_lshl_add, two VALU.  (Going through the generic
+// `tile` pointer costs a third: hipcc adds the LDS base, a link-time 0, with its own v_add.)
+typedef const uint16_t __attribute__((address_space(3))) *lds_u16_ptr;
+__device__ __forceinline__ uint32_t q_xread(const uint16_t * /*tile*/, uint32_t node, uint32_t posb)
 {
-    uint32_t r;
-    asm("v_lshrrev_b32 %0, 8, %1\n\tv_and_or_b32 %0, %0, %2, %3" : "=&v"(r) : "v"(node), "s"(0x7fff00u), "v"(pos2));
-    return r;
-}
-__device__ __forceinline__ uint32_t q_xread(const uint16_t *tile, uint32_t node, uint32_t pos2)
-{
-    return *reinterpret_cast<const uint16_t *>(reinterpret_cast<const unsigned char *>(tile) + q_xoff(node, pos2));
+    uint32_t addr;  // asm: hipcc re-canonicalises the C form into shift + and + add
+    asm("v_bfe_u32 %0, %1, 16, 15\n\tv_lshl_add_u32 %0, %0, 8, %2" : "=&v"(addr) : "v"(node), "v"(posb));
+    return *reinterpret_cast<lds_u16_ptr>(addr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -393,7 +392,8 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
         constexpr bool MS = decltype(ms_tag)::value;
         uint32_t pos[K];  // byte position of this lane's row inside a 256-byte feature column, per chain
     #pragma unroll
-        for (int k = 0; k < K; ++k) pos[k] = 2u * (uint32_t)qrow_pos(k * 64 + lane);
+        for (int k = 0; k < K; ++k)  // low 32 bits of a generic LDS pointer = the LDS byte address
+            pos[k] = (uint32_t)reinterpret_cast<uintptr_t>(tile) + 2u * (uint32_t)qrow_pos(k * 64 + lane);
         const size_t n_inner = ((size_t)1 << depth) - 1;
         const uint32_t n_blocks = 1u << (depth - 2);
         const uint32_t first_block_node = n_blocks - 1;
