@@ -116,6 +116,32 @@ tahoe_status tahoe_forest_create(tahoe_forest **out, const tahoe_dense_node *nod
                                  const tahoe_forest_params *params);
 void tahoe_forest_destroy(tahoe_forest *f);
 
+/* ---- sparse (irregular) forests: sparse_node_t Struct.h:50-54, sparse_storage Struct.h:343-354,
+ * init_sparse / sparse_forest::init (BaseTahoeTest.h:766-772, Struct.h:2329-2343) ---- */
+typedef struct {
+    float val;        /* threshold, or the output of a leaf */
+    int32_t bits;     /* fid[0:29] | def_left<<30 | is_leaf<<31 (sparse_node_init, BaseTahoeTest.h:719-724) */
+    int32_t left_idx; /* left child, relative to the tree's root; the right child is left_idx + 1 */
+} tahoe_sparse_node;
+
+/* trees[t] = offset of tree t's root in nodes[] (ascending); params->num_nodes = total nodes; params->depth is
+ * ignored.  The handle is used with the same tahoe_forest_predict* / destroy entry points; leaf indices are
+ * relative to the tree's root.  The walk is infer_one_tree_sparse (Struct.h:2217-2250) with the branch rule of
+ * the live dense path (BaseTahoeTest.h:452), so a forest converted with tahoe_dense_to_sparse predicts exactly
+ * what the dense forest predicts.  Rejects (TAHOE_ERR_INVALID_FOREST) child links that leave the tree or point
+ * backwards, and fid >= num_cols. */
+tahoe_status tahoe_sparse_forest_create(tahoe_forest **out, const int32_t *trees, const tahoe_sparse_node *nodes,
+                                        const tahoe_forest_params *params);
+/* dense2sparse (BaseTahoeTest.h:728-764).  *nodes_out / *trees_out: tahoe_free_host. */
+tahoe_status tahoe_dense_to_sparse(const tahoe_dense_node *dense, int num_trees, int depth,
+                                   tahoe_sparse_node **nodes_out, int32_t **trees_out, size_t *num_nodes_out);
+/* Deterministic irregular forest (BASELINE config 5): per tree a depth limit in [min_depth, max_depth]; nodes
+ * below min_depth become leaves with probability leaf_prob; at most max_tree_nodes per tree.  With nodes == NULL
+ * only *num_nodes is computed (call twice). */
+tahoe_status tahoe_synth_sparse_forest(tahoe_sparse_node *nodes, int32_t *trees, size_t *num_nodes, int num_trees,
+                                       int num_cols, int min_depth, int max_depth, float leaf_prob,
+                                       int max_tree_nodes, uint64_t seed);
+
 /* preds_dev[rows] <- per-row float32 sum of leaf values in tree order 0..T-1 (the order of
  * predict_on_cpu, BaseTahoeTest.h:462-466), then AVG / bias / sigmoid / threshold as
  * forest::predict + transform_k do (Struct.h:196-209, :263-268).  data_dev is row-major
@@ -162,6 +188,7 @@ typedef struct {
     int tileblock_lds_bytes; /* dynamic LDS of the TILEBLOCK kernel */
     int qring_walkers;       /* walker waves of the QRING kernel; 0 = strategy unavailable */
     int qring_lds_bytes;     /* dynamic LDS of the QRING kernel */
+    int is_sparse;           /* 1: handle made by tahoe_sparse_forest_create (only the generic fields are set) */
     int ring_rows;           /* rows per TILERING tile: 64, 128, or 0 = strategy unavailable */
     int tilering_lds_bytes;  /* dynamic LDS of the TILERING kernel */
 } tahoe_forest_info;

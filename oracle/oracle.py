@@ -113,3 +113,47 @@ def predict_f64(nodes: np.ndarray, num_trees: int, depth: int, data: np.ndarray,
     lib.oracle_predict_f64(nodes.ctypes.data, num_trees, depth, data.ctypes.data, 0, rows, cols, missing,
                            sums.ctypes.data)
     return sums
+
+
+# ---- sparse forests (Struct.h:50-54, 2217-2250; BaseTahoeTest.h:728-764) ----
+SPARSE_NODE_DTYPE = np.dtype([("val", "<f4"), ("bits", "<i4"), ("left_idx", "<i4")])
+lib.oracle_sparse_predict.restype = None
+lib.oracle_sparse_predict.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int,
+                                      C.c_float, C.c_void_p, C.c_void_p]
+lib.oracle_dense_to_sparse.restype = C.c_size_t
+lib.oracle_dense_to_sparse.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+
+
+def sparse_predict(nodes: np.ndarray, trees: np.ndarray, data: np.ndarray, missing: float, want_leaf: bool = False,
+                   threads: int = 1):
+    nodes = np.ascontiguousarray(nodes, dtype=SPARSE_NODE_DTYPE)
+    trees = np.ascontiguousarray(trees, dtype=np.int32)
+    data = np.ascontiguousarray(data, dtype=np.float32)
+    rows, cols = data.shape
+    preds = np.empty(rows, dtype=np.float32)
+    leaf = np.empty((rows, trees.size), dtype=np.uint32) if want_leaf else None
+
+    def run(lo, hi):
+        lib.oracle_sparse_predict(nodes.ctypes.data, trees.ctypes.data, trees.size, data.ctypes.data, lo, hi, cols, missing,
+                                  preds.ctypes.data, leaf.ctypes.data if want_leaf else None)
+
+    if threads <= 1 or rows < 2 * threads:
+        run(0, rows)
+    else:
+        bounds = np.linspace(0, rows, threads + 1).astype(np.int64)
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(lambda k: run(int(bounds[k]), int(bounds[k + 1])), range(threads)))
+    return preds, leaf
+
+
+def dense_to_sparse(nodes: np.ndarray, num_trees: int, depth: int):
+    nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
+    pn, pt = C.c_void_p(), C.c_void_p()
+    n = lib.oracle_dense_to_sparse(nodes.ctypes.data, num_trees, depth, C.byref(pn), C.byref(pt))
+    try:
+        sn = np.frombuffer((C.c_char * (n * 12)).from_address(pn.value), dtype=SPARSE_NODE_DTYPE, count=n).copy()
+        tr = np.frombuffer((C.c_char * (num_trees * 4)).from_address(pt.value), dtype=np.int32, count=num_trees).copy()
+    finally:
+        lib.oracle_free(pn)
+        lib.oracle_free(pt)
+    return sn, tr

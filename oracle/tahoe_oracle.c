@@ -160,3 +160,94 @@ void oracle_predict_f64(const oracle_node *nodes, int num_trees, int depth, cons
         sums[i] = s;
     }
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Sparse forests (dead code in the reference; the only reference-defined format that can hold the
+ * irregular config K5).  See tahoe_oracle.h for the choice of branch rule. */
+float oracle_sparse_infer_one_tree(const oracle_sparse_node *root, const float *row, float missing, uint32_t *leaf_idx)
+{
+    /* Struct.h:2217-2250 with NITEMS = 1 */
+    unsigned int curr = 0;                                  /* :2221 */
+    for (;;) {
+        const float n_val = root[curr].val;                 /* :2226 */
+        const int32_t n_bits = root[curr].bits;             /* :2227 */
+        const int n_fid = n_bits & FID_MASK;                /* :2230 */
+        const int n_def_left = (n_bits & DEF_LEFT_MASK) != 0; /* :2231 */
+        const int n_is_leaf = (n_bits & IS_LEAF_MASK) != 0; /* :2232 */
+        if (n_is_leaf) break;                               /* :2234-2237 */
+        const float val = row[n_fid];                       /* :2239 */
+        const float eps = 1.0e-6f;
+        const int cond = (fabsf(val - missing) <= eps) ? !n_def_left : (val >= n_val); /* live rule, BaseTahoeTest.h:452 */
+        curr = (unsigned int)(root[curr].left_idx + cond);  /* :2244 */
+    }
+    if (leaf_idx) *leaf_idx = curr;
+    return root[curr].val;                                  /* :2249 */
+}
+
+void oracle_sparse_predict(const oracle_sparse_node *nodes, const int32_t *trees, int num_trees, const float *data,
+                           size_t row_begin, size_t row_end, int num_cols, float missing, float *preds,
+                           uint32_t *leaf_idx)
+{
+    for (size_t i = row_begin; i < row_end; ++i) {
+        float pred = 0.0f;
+        for (int j = 0; j < num_trees; ++j) { /* trees in order, float32 += (infer_k, Struct.h:2271-2273, made sequential) */
+            uint32_t li;
+            pred += oracle_sparse_infer_one_tree(&nodes[trees[j]], &data[i * (size_t)num_cols], missing, &li);
+            if (leaf_idx) leaf_idx[i * (size_t)num_trees + (size_t)j] = li;
+        }
+        if (preds) preds[i] = pred;
+    }
+}
+
+typedef struct {
+    oracle_sparse_node *nodes;
+    size_t size, cap;
+} sparse_vec;
+
+static size_t sv_push(sparse_vec *v)
+{
+    if (v->size == v->cap) {
+        v->cap = v->cap ? v->cap * 2 : 1024;
+        v->nodes = (oracle_sparse_node *)realloc(v->nodes, v->cap * sizeof(oracle_sparse_node));
+    }
+    memset(&v->nodes[v->size], 0, sizeof(oracle_sparse_node));
+    return v->size++;
+}
+
+static void d2s_node(const oracle_node *dense_root, size_t i_dense, size_t i_sparse_root, size_t i_sparse, sparse_vec *v)
+{
+    /* dense2sparse_node, BaseTahoeTest.h:728-752 */
+    float value, weight;
+    int fid, def_left, is_leaf;
+    oracle_decode_node(&dense_root[i_dense], &value, &weight, &fid, &def_left, &is_leaf);
+    if (is_leaf) {                                            /* :735-740 */
+        v->nodes[i_sparse].val = value;
+        v->nodes[i_sparse].bits = (fid & FID_MASK) | (def_left ? DEF_LEFT_MASK : 0) | IS_LEAF_MASK;
+        v->nodes[i_sparse].left_idx = 0;
+        return;
+    }
+    const size_t left_index = sv_push(v);                     /* :743-745 reserve both children */
+    (void)sv_push(v);
+    v->nodes[i_sparse].val = value;
+    v->nodes[i_sparse].bits = (fid & FID_MASK) | (def_left ? DEF_LEFT_MASK : 0);
+    v->nodes[i_sparse].left_idx = (int32_t)(left_index - i_sparse_root); /* :746-747 */
+    d2s_node(dense_root, 2 * i_dense + 1, i_sparse_root, left_index, v);      /* :748 */
+    d2s_node(dense_root, 2 * i_dense + 2, i_sparse_root, left_index + 1, v);  /* :749-750 */
+}
+
+size_t oracle_dense_to_sparse(const oracle_node *dense, int num_trees, int depth, oracle_sparse_node **nodes_out,
+                              int32_t **trees_out)
+{
+    /* dense2sparse / dense2sparse_tree, BaseTahoeTest.h:754-764 */
+    sparse_vec v = {NULL, 0, 0};
+    int32_t *trees = (int32_t *)malloc((num_trees ? num_trees : 1) * sizeof(int32_t));
+    const size_t per_tree = (size_t)oracle_tree_num_nodes(depth);
+    for (int t = 0; t < num_trees; ++t) {
+        const size_t root = sv_push(&v);
+        d2s_node(&dense[(size_t)t * per_tree], 0, root, root, &v);
+        trees[t] = (int32_t)root;
+    }
+    *nodes_out = v.nodes;
+    *trees_out = trees;
+    return v.size;
+}

@@ -68,6 +68,31 @@ void oracle_predict(const oracle_node *nodes, int num_trees, int depth, const fl
 void oracle_predict_f64(const oracle_node *nodes, int num_trees, int depth, const float *data,
                         size_t row_begin, size_t row_end, int num_cols, float missing, double *sums);
 
+/* ---- sparse forests: sparse_node_t (Struct.h:50-54), sparse_tree / sparse_storage (Struct.h:334-354) ---- */
+typedef struct {
+    float val;        /* threshold, or the output of a leaf */
+    int32_t bits;     /* fid | def_left<<30 | is_leaf<<31 (sparse_node_init, BaseTahoeTest.h:719-724) */
+    int32_t left_idx; /* index of the left child relative to the tree's root; right child = left_idx + 1 */
+} oracle_sparse_node;
+
+/* The walk of infer_one_tree_sparse (Struct.h:2217-2250): curr = 0; until a leaf: curr = left_idx + cond.
+ * The branch rule is the one of the LIVE path (BaseTahoeTest.h:452: |x - missing| <= 1e-6 ? !def_left : x >= thr),
+ * not the isnan() of the dead sparse kernel (Struct.h:2240): the reference's own (commented) sparse harness checks
+ * the sparse forest against predict_on_cpu of the dense forest it was converted from (BaseTahoeTest.h:746-764, 836),
+ * which only holds with the live rule.  *leaf_idx = final curr (relative to the tree's root). */
+float oracle_sparse_infer_one_tree(const oracle_sparse_node *root, const float *row, float missing, uint32_t *leaf_idx);
+
+/* Per-row float32 sum in tree order over trees[t] = root offset of tree t (sparse_storage::operator[], Struct.h:351-353),
+ * rows [row_begin, row_end); preds / leaf_idx as in oracle_predict (RAW output). */
+void oracle_sparse_predict(const oracle_sparse_node *nodes, const int32_t *trees, int num_trees, const float *data,
+                           size_t row_begin, size_t row_end, int num_cols, float missing, float *preds,
+                           uint32_t *leaf_idx);
+
+/* dense2sparse (BaseTahoeTest.h:728-764): converts one dense forest; *nodes_out / *trees_out are malloc'd;
+ * returns the number of sparse nodes. */
+size_t oracle_dense_to_sparse(const oracle_node *dense, int num_trees, int depth, oracle_sparse_node **nodes_out,
+                              int32_t **trees_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -83,6 +83,7 @@ class ForestInfo(C.Structure):
         ("tileblock_lds_bytes", C.c_int),
         ("qring_walkers", C.c_int),
         ("qring_lds_bytes", C.c_int),
+        ("is_sparse", C.c_int),
         ("ring_rows", C.c_int),
         ("tilering_lds_bytes", C.c_int),
     ]
@@ -109,6 +110,9 @@ _PROTOS = {
     "tahoe_tree_num_nodes": (_i, [_i]),
     "tahoe_forest_create": (_i, [C.POINTER(_vp), _vp, C.POINTER(ForestParams)]),
     "tahoe_forest_destroy": (None, [_vp]),
+    "tahoe_sparse_forest_create": (_i, [C.POINTER(_vp), _vp, _vp, C.POINTER(ForestParams)]),
+    "tahoe_dense_to_sparse": (_i, [_vp, _i, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_sz)]),
+    "tahoe_synth_sparse_forest": (_i, [_vp, _vp, C.POINTER(_sz), _i, _i, _i, _i, _f, _i, C.c_uint64]),
     "tahoe_forest_predict": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "tahoe_forest_predict_raw": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "tahoe_forest_predict_leaf_idx": (_i, [_vp, _vp, _vp, _vp, _sz, _vp]),
@@ -332,6 +336,55 @@ class Forest:
         _check(lib.tahoe_forest_prepass_times(self._h, out.ctypes.data, capacity, C.byref(n)),
                "tahoe_forest_prepass_times")
         return out[: n.value].copy()
+
+
+# ---- sparse (irregular) forests ----
+SPARSE_NODE_DTYPE = np.dtype([("val", "<f4"), ("bits", "<i4"), ("left_idx", "<i4")])  # sparse_node_t, Struct.h:50-54
+
+
+def dense_to_sparse(nodes: np.ndarray, num_trees: int, depth: int):
+    """dense2sparse (BaseTahoeTest.h:728-764) -> (sparse nodes, root offsets int32[num_trees])."""
+    nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
+    pn, pt, n = _vp(), _vp(), _sz()
+    _check(lib.tahoe_dense_to_sparse(nodes.ctypes.data, num_trees, depth, C.byref(pn), C.byref(pt), C.byref(n)),
+           "tahoe_dense_to_sparse")
+    try:
+        sn = np.frombuffer((C.c_char * (n.value * 12)).from_address(pn.value), dtype=SPARSE_NODE_DTYPE, count=n.value).copy()
+        tr = np.frombuffer((C.c_char * (num_trees * 4)).from_address(pt.value), dtype=np.int32, count=num_trees).copy() \
+            if num_trees else np.empty(0, np.int32)
+    finally:
+        lib.tahoe_free_host(pn)
+        lib.tahoe_free_host(pt)
+    return sn, tr
+
+
+def synth_sparse_forest(num_trees: int, num_cols: int, min_depth: int = 4, max_depth: int = 24, leaf_prob: float = 0.32,
+                        max_tree_nodes: int = 65535, seed: int = 44):
+    """BASELINE config 5 generator -> (sparse nodes, root offsets)."""
+    n = _sz()
+    _check(lib.tahoe_synth_sparse_forest(None, None, C.byref(n), num_trees, num_cols, min_depth, max_depth, leaf_prob,
+                                         max_tree_nodes, seed), "tahoe_synth_sparse_forest")
+    nodes = np.empty(n.value, dtype=SPARSE_NODE_DTYPE)
+    trees = np.empty(num_trees, dtype=np.int32)
+    _check(lib.tahoe_synth_sparse_forest(nodes.ctypes.data, trees.ctypes.data, C.byref(n), num_trees, num_cols, min_depth,
+                                         max_depth, leaf_prob, max_tree_nodes, seed), "tahoe_synth_sparse_forest")
+    return nodes, trees
+
+
+class SparseForest(Forest):
+    """tahoe_sparse_forest_create: nodes[SPARSE_NODE_DTYPE] + root offsets; predict* as Forest."""
+
+    def __init__(self, nodes: np.ndarray, trees: np.ndarray, num_cols: int, missing: float = 0.0, output: int = OUT_RAW,
+                 threshold: float = 0.0, global_bias: float = 0.0):
+        nodes = np.ascontiguousarray(nodes, dtype=SPARSE_NODE_DTYPE)
+        trees = np.ascontiguousarray(trees, dtype=np.int32)
+        self.params = ForestParams(int(nodes.size), 0, int(trees.size), num_cols, 0, output, threshold, global_bias, 0,
+                                   missing)
+        self._h = _vp()
+        _check(lib.tahoe_sparse_forest_create(C.byref(self._h), trees.ctypes.data if trees.size else None,
+                                              nodes.ctypes.data if nodes.size else None, C.byref(self.params)),
+               "tahoe_sparse_forest_create")
+        self.num_trees, self.depth, self.num_cols = int(trees.size), 0, num_cols
 
 
 def transform_preds(preds, output: int, num_trees_total: int, threshold: float, global_bias: float, stream=None):

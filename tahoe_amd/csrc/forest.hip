@@ -38,13 +38,7 @@
 namespace tahoe {
 
 // ------------------------------------------------------------------------------------------------
-// The branch rule of infer_one_tree, BaseTahoeTest.h:450-453: 1 = right child.
-__device__ __forceinline__ uint32_t go_right(float x, float thr, bool def_left, float missing)
-{
-    const bool is_missing = fabsf(x - missing) <= kMissingEps;
-    const bool cond = is_missing ? !def_left : (x >= thr);
-    return cond ? 1u : 0u;
-}
+// (go_right, the branch rule, lives in forest_internal.h)
 __device__ __forceinline__ uint32_t step(uint32_t idx, float thr, uint32_t meta, float x, float missing)
 {
     return 2u * idx + 1u + go_right(x, thr, (meta >> 31) != 0, missing);
@@ -703,6 +697,10 @@ static int tilering_rows(const tahoe_forest *f)
 
 static int resolve_strategy(const tahoe_forest *f, size_t /*rows*/)
 {
+    if (f->sp) {  // sparse handle: ROWTILE = 64-row tile in LDS, DIRECT = features from global memory
+        if (f->strategy == TAHOE_STRATEGY_DIRECT) return TAHOE_STRATEGY_DIRECT;
+        return sparse_tile_fits(f) ? TAHOE_STRATEGY_ROWTILE : TAHOE_STRATEGY_DIRECT;
+    }
     if (f->strategy != TAHOE_STRATEGY_AUTO) return f->strategy;
     if (qring_walkers(f) > 0) return TAHOE_STRATEGY_QRING;
     if (tilering_rows(f) > 0) return TAHOE_STRATEGY_TILERING;
@@ -757,6 +755,9 @@ static tahoe_status launch_traversal(tahoe_forest *f, float *sums, uint32_t *lea
     if (f->p.num_trees == 0) {
         // Nothing to walk: sums are zero (an empty j-loop in predict_on_cpu).
         if (sums) TAHOE_HIP_TRY(hipMemsetAsync(sums, 0, rows * sizeof(float), stream));
+    } else if (f->sp) {
+        const tahoe_status ss = sparse_launch(f, sums, leaf_out, data, rows, stream, strategy == TAHOE_STRATEGY_ROWTILE);
+        if (ss != TAHOE_OK) return ss;
     } else if (strategy == TAHOE_STRATEGY_QRING) {
         const tahoe_status qs = qring_launch(f, sums, leaf_out, data, rows, stream, timed ? f->ev_mid[f->prof_count] : nullptr);
         mid_recorded = timed;
@@ -1065,6 +1066,7 @@ void tahoe_forest_destroy(tahoe_forest *f)
     if (f->blocks) (void)hipFree(f->blocks);
     if (f->error_flag) (void)hipFree(f->error_flag);
     qring_destroy(f);
+    sparse_destroy(f);
     for (hipEvent_t e : f->ev_start) (void)hipEventDestroy(e);
     for (hipEvent_t e : f->ev_mid) (void)hipEventDestroy(e);
     for (hipEvent_t e : f->ev_stop) (void)hipEventDestroy(e);
@@ -1110,6 +1112,12 @@ tahoe_status tahoe_forest_set_strategy(tahoe_forest *f, int strategy)
     if (!f) return fail(TAHOE_ERR_INVALID_ARG, "null forest");
     if (strategy < TAHOE_STRATEGY_AUTO || strategy > TAHOE_STRATEGY_QRING)
         return fail(TAHOE_ERR_INVALID_ARG, "unknown strategy %d", strategy);
+    if (f->sp) {
+        if (strategy > TAHOE_STRATEGY_ROWTILE || (strategy == TAHOE_STRATEGY_ROWTILE && !sparse_tile_fits(f)))
+            return fail(TAHOE_ERR_UNSUPPORTED, "a sparse forest runs AUTO, DIRECT or (when a 64-row tile fits LDS) ROWTILE");
+        f->strategy = strategy;
+        return TAHOE_OK;
+    }
     if (strategy == TAHOE_STRATEGY_ROWTILE && !rowtile_fits(f))
         return fail(TAHOE_ERR_UNSUPPORTED, "ROWTILE needs %d B of LDS for %d columns; device offers %d",
                     rowtile_lds_bytes(f->p.num_cols, f->lds_levels), f->p.num_cols, f->lds_limit);
@@ -1150,6 +1158,16 @@ tahoe_status tahoe_forest_get_info(const tahoe_forest *f, tahoe_forest_info *inf
 {
     if (!f || !info) return fail(TAHOE_ERR_INVALID_ARG, "null argument");
     memset(info, 0, sizeof(*info));
+    info->is_sparse = f->sp != nullptr;
+    if (f->sp) {
+        info->num_trees = f->p.num_trees;
+        info->num_cols = f->p.num_cols;
+        info->bits_bytes = f->bits_bytes;
+        info->device_bytes = f->device_bytes;
+        info->device_id = f->device;
+        info->num_cus = f->num_cus;
+        return TAHOE_OK;
+    }
     info->num_trees = f->p.num_trees;
     info->depth = f->p.depth;
     info->num_cols = f->p.num_cols;

@@ -9,6 +9,7 @@
 #include "common.h"
 
 struct tahoe_qstate;  // quantised views + workspace, owned by qring.hip
+struct tahoe_sstate;  // sparse (irregular) forest, owned by sparse.hip
 
 namespace tahoe {
 
@@ -62,6 +63,7 @@ struct tahoe_forest {
     uint4 *blocks = nullptr;       // [T][2^(De-2)][2]
     int *error_flag = nullptr;     // set by TILERING if a bounded spin ever times out
     tahoe_qstate *q = nullptr;     // QRING: rank-quantised forest + row workspace (qring.hip)
+    tahoe_sstate *sp = nullptr;    // non-null: this handle is a sparse forest (sparse.hip); the dense views are unused
     size_t device_bytes = 0;
     // Profiling: one hipEvent pair per traversal launch, read back after the stream has drained.
     bool profiling = false;
@@ -70,6 +72,14 @@ struct tahoe_forest {
 };
 
 namespace tahoe {
+
+// The branch rule of infer_one_tree, BaseTahoeTest.h:450-453: 1 = right child.
+__device__ __forceinline__ uint32_t go_right(float x, float thr, bool def_left, float missing)
+{
+    const bool is_missing = fabsf(x - missing) <= kMissingEps;
+    const bool cond = is_missing ? !def_left : (x >= thr);
+    return cond ? 1u : 0u;
+}
 
 // QRING entry points (qring.hip).  h_real[i] != 0 marks heap records that exist in the original tree
 // (padding below an early leaf is not real and contributes no threshold).
@@ -82,5 +92,11 @@ long long qring_lds_bytes(const tahoe_forest *f);
 tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, const float *data, size_t rows,
                           hipStream_t stream, hipEvent_t mid_event);
 tahoe_status qring_reserve(tahoe_forest *f, size_t rows);
+
+// sparse forests (sparse.hip)
+bool sparse_tile_fits(const tahoe_forest *f);
+tahoe_status sparse_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, const float *data, size_t rows,
+                           hipStream_t stream, bool tile);
+void sparse_destroy(tahoe_forest *f);
 
 }  // namespace tahoe

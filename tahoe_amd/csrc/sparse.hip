@@ -1,0 +1,337 @@
+// Sparse (irregular) forests: the reference's sparse_node_t / sparse_storage (Struct.h:50-54, 334-354), the
+// walker infer_one_tree_sparse (Struct.h:2217-2250) and sparse_forest (Struct.h:2327-2353), plus the
+// dense -> sparse converter of the (commented-out) harness (BaseTahoeTest.h:728-764).  Dead code in the
+// reference, but the only reference-defined format that can hold trees of depth 4..24 (config K5): a dense
+// depth-24 tree would need 2^25 nodes.
+//
+// Branch rule: the live one (BaseTahoeTest.h:452, |x - missing| <= 1e-6 ? !def_left : x >= thr), not the
+// isnan() of the dead kernel (Struct.h:2240) -- a forest converted with dense2sparse must predict exactly
+// what predict_on_cpu predicts for the dense original, which is the check the reference's own sparse
+// harness makes (BaseTahoeTest.h:836).
+//
+// Kernels: lane = row, the four waves of a workgroup split the trees round-robin, leaf values cross LDS
+// once per round of four trees and are added by the row's owner lane in tree order (float32 sums bit-equal
+// to a sequential CPU sum).  A walk is a chain of dependent 12-byte node gathers from L2 / Infinity Cache;
+// lanes that have reached their leaf idle until the longest path of the wave ends (wave divergence is
+// inherent to irregular trees).  With TILE the 64 rows sit feature-major in LDS (any per-lane fid is
+// bank-conflict free), else features come from global memory.
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "forest_internal.h"
+
+struct tahoe_sstate {
+    tahoe_sparse_node *nodes = nullptr;  // device copy, as given
+    int32_t *trees = nullptr;            // device: root offset per tree
+    size_t num_nodes = 0;
+    int max_tree_nodes = 0;
+};
+
+namespace tahoe {
+
+constexpr int32_t kSFidMask = (int32_t)((1u << 30) - 1u);
+constexpr int32_t kSDefLeft = (int32_t)(1u << 30);
+constexpr int32_t kSIsLeaf = (int32_t)(1u << 31);
+
+template <bool TILE, bool WRITE_LEAF>
+__global__ void __launch_bounds__(kBlock) sparse_kernel(const tahoe_sparse_node *__restrict__ nodes,
+                                                        const int32_t *__restrict__ trees, const float *__restrict__ data,
+                                                        float *__restrict__ sums, uint32_t *__restrict__ leaf_out,
+                                                        size_t rows, int cols, int num_trees, float missing, int vec4_ok)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float *tile = reinterpret_cast<float *>(smem);
+    float *vals = reinterpret_cast<float *>(smem + (TILE ? (size_t)cols * kTileRows * sizeof(float) : 0));
+    const size_t row0 = (size_t)blockIdx.x * kTileRows;
+    const size_t row = row0 + lane;
+    const bool row_ok = row < rows;
+    const float *xrow = data + (row_ok ? row : row0) * (size_t)cols;
+    if (TILE) {
+        if (vec4_ok) {
+            const float4 *src4 = reinterpret_cast<const float4 *>(xrow);
+            for (int f4 = wave; f4 < cols / 4; f4 += kWaves) {
+                const float4 v = row_ok ? src4[f4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                tile[(4 * f4 + 0) * kTileRows + lane] = v.x;
+                tile[(4 * f4 + 1) * kTileRows + lane] = v.y;
+                tile[(4 * f4 + 2) * kTileRows + lane] = v.z;
+                tile[(4 * f4 + 3) * kTileRows + lane] = v.w;
+            }
+        } else {
+            for (int f = wave; f < cols; f += kWaves) tile[f * kTileRows + lane] = row_ok ? xrow[f] : 0.0f;
+        }
+        __syncthreads();
+    }
+    float sum = 0.0f;  // lanes 0..15: row 16*wave + lane of the tile
+    const int rounds = (num_trees + kWaves - 1) / kWaves;
+    for (int r = 0; r < rounds; ++r) {
+        const int t = r * kWaves + wave;
+        float v = 0.0f;
+        if (t < num_trees) {
+            const tahoe_sparse_node *root = nodes + trees[t];
+            uint32_t curr = 0;
+            for (;;) {  // create() guarantees left_idx > curr and in range: the walk terminates
+                const tahoe_sparse_node n = root[curr];
+                if (n.bits & kSIsLeaf) {
+                    v = n.val;
+                    break;
+                }
+                const int fid = n.bits & kSFidMask;
+                const float x = TILE ? tile[fid * kTileRows + lane] : xrow[fid];
+                curr = (uint32_t)n.left_idx + go_right(x, n.val, (n.bits & kSDefLeft) != 0, missing);
+            }
+            if (WRITE_LEAF) {
+                if (row_ok) leaf_out[row * (size_t)num_trees + t] = curr;
+            }
+        }
+        float *vb = vals + (size_t)(r & 1) * kWaves * kTileRows;
+        vb[wave * kTileRows + lane] = v;
+        __syncthreads();
+        if (lane < 16) {
+            const int rr = 16 * wave + lane;
+            const int nt = min(kWaves, num_trees - r * kWaves);
+            for (int j = 0; j < nt; ++j) sum += vb[j * kTileRows + rr];  // tree order
+        }
+    }
+    if (sums && lane < 16) {
+        const size_t orow = row0 + 16 * wave + lane;
+        if (orow < rows) sums[orow] = sum;
+    }
+}
+
+static long long sparse_lds(const tahoe_forest *f, bool tile)
+{
+    return (tile ? (long long)f->p.num_cols * kTileRows * 4 : 0) + 2LL * kWaves * kTileRows * 4;
+}
+
+bool sparse_tile_fits(const tahoe_forest *f) { return f->p.num_cols >= 1 && sparse_lds(f, true) <= f->lds_limit; }
+
+tahoe_status sparse_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, const float *data, size_t rows,
+                           hipStream_t stream, bool tile)
+{
+    const tahoe_sstate *sp = f->sp;
+    const unsigned grid = (unsigned)((rows + kTileRows - 1) / kTileRows);
+    const int vec4_ok = (f->p.num_cols % 4 == 0) && ((reinterpret_cast<uintptr_t>(data) & 15u) == 0);
+    const int lds = (int)sparse_lds(f, tile);
+#define TAHOE_SPARSE_LAUNCH(TILE_, LEAF_)                                                                            \
+    hipLaunchKernelGGL((sparse_kernel<TILE_, LEAF_>), dim3(grid), dim3(kBlock), lds, stream, sp->nodes, sp->trees, data, \
+                       sums, leaf_out, rows, f->p.num_cols, f->p.num_trees, f->p.missing, vec4_ok)
+    if (tile) {
+        if (leaf_out)
+            TAHOE_SPARSE_LAUNCH(true, true);
+        else
+            TAHOE_SPARSE_LAUNCH(true, false);
+    } else {
+        if (leaf_out)
+            TAHOE_SPARSE_LAUNCH(false, true);
+        else
+            TAHOE_SPARSE_LAUNCH(false, false);
+    }
+#undef TAHOE_SPARSE_LAUNCH
+    TAHOE_HIP_TRY(hipGetLastError());
+    return TAHOE_OK;
+}
+
+void sparse_destroy(tahoe_forest *f)
+{
+    if (!f->sp) return;
+    if (f->sp->nodes) (void)hipFree(f->sp->nodes);
+    if (f->sp->trees) (void)hipFree(f->sp->trees);
+    delete f->sp;
+    f->sp = nullptr;
+}
+
+}  // namespace tahoe
+
+using namespace tahoe;
+
+extern "C" {
+
+tahoe_status tahoe_sparse_forest_create(tahoe_forest **out, const int32_t *trees, const tahoe_sparse_node *nodes,
+                                        const tahoe_forest_params *p)
+{
+    if (!out || !p) return fail(TAHOE_ERR_INVALID_ARG, "tahoe_sparse_forest_create: null argument");
+    *out = nullptr;
+    // check_params(params, dense = false), BaseTahoeTest.h:490-516
+    if (p->num_nodes < 0) return fail(TAHOE_ERR_INVALID_ARG, "num_nodes must be non-negative for sparse forests");
+    if (p->algo != TAHOE_ALGO_NAIVE) return fail(TAHOE_ERR_INVALID_ARG, "only NAIVE algorithm is supported for sparse forests");
+    if (p->num_trees < 0) return fail(TAHOE_ERR_INVALID_ARG, "num_trees must be non-negative");
+    if (p->num_cols < 0) return fail(TAHOE_ERR_INVALID_ARG, "num_cols must be non-negative");
+    if ((p->output & ~(TAHOE_OUT_AVG | TAHOE_OUT_SIGMOID | TAHOE_OUT_THRESHOLD)) != 0)
+        return fail(TAHOE_ERR_INVALID_ARG, "output should be a combination of RAW, AVG, SIGMOID and THRESHOLD");
+    if (p->num_trees > 0 && (!trees || !nodes)) return fail(TAHOE_ERR_INVALID_ARG, "trees / nodes is null");
+    // Structure check (the reference trusts its input): roots ascending, every child pair inside its tree
+    // and after its parent (which also rules out cycles, so device walks terminate), fid < num_cols.
+    int max_tree_nodes = 0;
+    for (int t = 0; t < p->num_trees; ++t) {
+        const long long lo = trees[t], hi = (t + 1 < p->num_trees) ? trees[t + 1] : p->num_nodes;
+        if (lo < 0 || hi <= lo || hi > p->num_nodes)
+            return fail(TAHOE_ERR_INVALID_FOREST, "tree %d: root offsets must be ascending and inside [0, num_nodes)", t);
+        max_tree_nodes = std::max(max_tree_nodes, (int)(hi - lo));
+        for (long long i = 0; i < hi - lo; ++i) {
+            const tahoe_sparse_node &n = nodes[lo + i];
+            if (n.bits & kSIsLeaf) continue;
+            if (n.left_idx <= i || (long long)n.left_idx + 1 >= hi - lo)
+                return fail(TAHOE_ERR_INVALID_FOREST, "tree %d node %lld: children %d, %d are not after the node and inside the tree",
+                            t, i, n.left_idx, n.left_idx + 1);
+            if ((n.bits & kSFidMask) >= p->num_cols)
+                return fail(TAHOE_ERR_INVALID_FOREST, "tree %d node %lld: fid %d >= num_cols %d", t, i, n.bits & kSFidMask,
+                            p->num_cols);
+        }
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(TAHOE_ERR_NO_DEVICE, "no HIP device is visible; libtahoe_amd has no CPU path");
+    int dev = 0;
+    TAHOE_HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    TAHOE_HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    tahoe_forest *f = new (std::nothrow) tahoe_forest();
+    tahoe_sstate *sp = new (std::nothrow) tahoe_sstate();
+    if (!f || !sp) {
+        delete f;
+        delete sp;
+        return fail(TAHOE_ERR_NO_MEMORY, "tahoe_sparse_forest_create");
+    }
+    f->sp = sp;
+    f->p = *p;
+    f->depth = 0;  // a placeholder value, as in sparse_forest::init (Struct.h:2332)
+    f->device = dev;
+    f->num_cus = prop.multiProcessorCount;
+    f->lds_limit = (int)prop.maxSharedMemoryPerMultiProcessor > 0 ? (int)prop.maxSharedMemoryPerMultiProcessor
+                                                                   : (int)prop.sharedMemPerBlock;
+    f->bits_bytes = 4;
+    sp->num_nodes = (size_t)p->num_nodes;
+    sp->max_tree_nodes = max_tree_nodes;
+    auto bail = [&](hipError_t e, const char *what) {
+        tahoe_forest_destroy(f);
+        return fail(TAHOE_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
+    };
+    hipError_t e;
+    const size_t nbytes = std::max<size_t>(sp->num_nodes, 1) * sizeof(tahoe_sparse_node);
+    const size_t tbytes = std::max<size_t>((size_t)p->num_trees, 1) * sizeof(int32_t);
+    if ((e = hipMalloc(reinterpret_cast<void **>(&sp->nodes), nbytes)) != hipSuccess) return bail(e, "hipMalloc(nodes)");
+    if ((e = hipMalloc(reinterpret_cast<void **>(&sp->trees), tbytes)) != hipSuccess) return bail(e, "hipMalloc(trees)");
+    f->device_bytes = nbytes + tbytes;
+    if (sp->num_nodes && (e = hipMemcpy(sp->nodes, nodes, sp->num_nodes * sizeof(tahoe_sparse_node), hipMemcpyHostToDevice)) != hipSuccess)
+        return bail(e, "hipMemcpy(nodes)");
+    if (p->num_trees && (e = hipMemcpy(sp->trees, trees, (size_t)p->num_trees * sizeof(int32_t), hipMemcpyHostToDevice)) != hipSuccess)
+        return bail(e, "hipMemcpy(trees)");
+    if (sparse_tile_fits(f)) {
+        const int lds = (int)sparse_lds(f, true);
+        if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sparse_kernel<true, false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess)
+            return bail(e, "hipFuncSetAttribute(sparse)");
+        if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sparse_kernel<true, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess)
+            return bail(e, "hipFuncSetAttribute(sparse)");
+    }
+    *out = f;
+    return TAHOE_OK;
+}
+
+// dense2sparse, BaseTahoeTest.h:728-764: per tree a root, then for every inner node its two children are
+// appended together (left_idx is relative to the tree's root) and converted depth-first, left first.
+tahoe_status tahoe_dense_to_sparse(const tahoe_dense_node *dense, int num_trees, int depth, tahoe_sparse_node **nodes_out,
+                                   int32_t **trees_out, size_t *num_nodes_out)
+{
+    if (!dense || !nodes_out || !trees_out || !num_nodes_out || num_trees < 0 || depth < 0 || depth > 30)
+        return fail(TAHOE_ERR_INVALID_ARG, "tahoe_dense_to_sparse: bad argument");
+    std::vector<tahoe_sparse_node> out;
+    std::vector<int32_t> roots((size_t)num_trees);
+    const size_t per_tree = (size_t)tahoe_tree_num_nodes(depth);
+    struct Item {
+        size_t i_dense, i_sparse;
+    };
+    std::vector<Item> stack;
+    for (int t = 0; t < num_trees; ++t) {
+        const tahoe_dense_node *root = dense + (size_t)t * per_tree;
+        const size_t i_root = out.size();
+        out.push_back(tahoe_sparse_node{0.f, 0, 0});
+        roots[(size_t)t] = (int32_t)i_root;
+        stack.assign(1, Item{0, i_root});
+        while (!stack.empty()) {
+            const Item it = stack.back();
+            stack.pop_back();
+            if (it.i_dense >= per_tree) return fail(TAHOE_ERR_INVALID_FOREST, "tree %d: a bottom-level node is not a leaf", t);
+            int fid, def_left, is_leaf;
+            float value;
+            tahoe_decode_node(&root[it.i_dense], &value, nullptr, &fid, &def_left, &is_leaf);
+            tahoe_sparse_node n;
+            n.val = value;
+            n.bits = (fid & kSFidMask) | (def_left ? kSDefLeft : 0) | (is_leaf ? kSIsLeaf : 0);
+            n.left_idx = 0;
+            if (!is_leaf) {
+                const size_t left = out.size();
+                out.push_back(tahoe_sparse_node{0.f, 0, 0});
+                out.push_back(tahoe_sparse_node{0.f, 0, 0});
+                n.left_idx = (int32_t)(left - i_root);
+                // depth-first, left subtree first: push right, then left
+                stack.push_back(Item{2 * it.i_dense + 2, left + 1});
+                stack.push_back(Item{2 * it.i_dense + 1, left});
+            }
+            out[it.i_sparse] = n;
+        }
+    }
+    tahoe_sparse_node *nodes = (tahoe_sparse_node *)malloc(std::max<size_t>(out.size(), 1) * sizeof(tahoe_sparse_node));
+    int32_t *trees = (int32_t *)malloc(std::max<size_t>(roots.size(), 1) * sizeof(int32_t));
+    if (!nodes || !trees) {
+        free(nodes);
+        free(trees);
+        return fail(TAHOE_ERR_NO_MEMORY, "tahoe_dense_to_sparse");
+    }
+    if (!out.empty()) memcpy(nodes, out.data(), out.size() * sizeof(tahoe_sparse_node));
+    if (!roots.empty()) memcpy(trees, roots.data(), roots.size() * sizeof(int32_t));
+    *nodes_out = nodes;
+    *trees_out = trees;
+    *num_nodes_out = out.size();
+    return TAHOE_OK;
+}
+
+// Synthetic irregular forest: tree t may grow to depth d_t = min_depth + (x mod (max_depth -
+// min_depth + 1)); levels < min_depth are always inner, below that a node turns into a leaf with probability
+// leaf_prob, level d_t is all leaves; at most max_tree_nodes per tree.  Children are appended in pairs,
+// breadth-first.  Call with nodes == NULL to get the node count for `seed` first.
+tahoe_status tahoe_synth_sparse_forest(tahoe_sparse_node *nodes, int32_t *trees, size_t *num_nodes, int num_trees,
+                                       int num_cols, int min_depth, int max_depth, float leaf_prob, int max_tree_nodes,
+                                       uint64_t seed)
+{
+    if (!num_nodes || num_trees < 0 || num_cols < 1 || min_depth < 0 || max_depth < min_depth || max_depth > 40 ||
+        max_tree_nodes < 3)
+        return fail(TAHOE_ERR_INVALID_ARG, "tahoe_synth_sparse_forest: bad argument");
+    size_t total = 0;
+    std::vector<int> level;  // level of each node of the current tree
+    for (int t = 0; t < num_trees; ++t) {
+        const uint64_t ts = splitmix64_at(seed, (uint64_t)t);
+        const int d_t = min_depth + (int)(splitmix64_at(ts, 0) % (uint64_t)(max_depth - min_depth + 1));
+        const size_t root = total;
+        if (trees) trees[t] = (int32_t)root;
+        level.assign(1, 0);
+        size_t count = 1;  // nodes allocated so far in this tree
+        for (size_t i = 0; i < count; ++i) {
+            const uint64_t x0 = splitmix64_at(ts, 4 * i + 1), x1 = splitmix64_at(ts, 4 * i + 2), x2 = splitmix64_at(ts, 4 * i + 3);
+            const int lv = level[i];
+            const bool room = count + 2 <= (size_t)max_tree_nodes;
+            const bool is_leaf = lv >= d_t || !room || (lv >= min_depth && u01(x2) < leaf_prob);
+            tahoe_sparse_node n;
+            n.val = 2.0f * u01(x1) - 1.0f;
+            n.bits = is_leaf ? kSIsLeaf : ((int32_t)(x0 % (uint64_t)num_cols) | ((x0 >> 40) & 1 ? kSDefLeft : 0));
+            n.left_idx = 0;
+            if (!is_leaf) {
+                n.left_idx = (int32_t)count;
+                level.push_back(lv + 1);
+                level.push_back(lv + 1);
+                count += 2;
+            }
+            if (nodes) nodes[root + i] = n;
+        }
+        total += count;
+    }
+    *num_nodes = total;
+    return TAHOE_OK;
+}
+
+}  // extern "C"

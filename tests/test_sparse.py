@@ -1,0 +1,98 @@
+"""Sparse (irregular) forests -- the reference's sparse_node_t format (Struct.h:50-54, 2217-2353), BASELINE config 5.
+CPU: the converter and the generator against the oracle's restatement.  GPU: the HIP walk against the oracle."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+
+MISSING = -999.0
+
+
+@pytest.fixture(scope="module")
+def ta(built):
+    import tahoe_amd
+
+    return tahoe_amd
+
+
+def test_dense_to_sparse_matches_the_oracle_converter_and_predicts_like_dense(ta):
+    T, D, C, R = 9, 6, 11, 300
+    nodes = ta.synth_forest(T, D, C, seed=3, leaf_prob=0.2)
+    data = ta.synth_data(R, C, seed=4, missing_prob=0.1, missing=MISSING, nan_prob=0.05)
+    sn, tr = ta.capi.dense_to_sparse(nodes, T, D)
+    on, ot = oracle.dense_to_sparse(nodes, T, D)
+    assert sn.tobytes() == on.tobytes() and tr.tobytes() == ot.tobytes()
+    # children are adjacent and after their parent; every tree starts at its root offset
+    inner = (sn["bits"].view(np.uint32) >> 31) == 0
+    assert (sn["left_idx"][inner] > 0).all()
+    dense_pred, _ = oracle.predict(nodes, T, D, data, MISSING)
+    sparse_pred, leaf = oracle.sparse_predict(sn, tr, data, MISSING, want_leaf=True)
+    assert np.array_equal(dense_pred.view(np.uint32), sparse_pred.view(np.uint32))
+    # the leaf a row ends in holds the value the dense walk returned
+    t0 = sn["val"][tr[0] + leaf[:, 0]]
+    _, dleaf = oracle.predict(nodes, T, D, data, MISSING, want_leaf=True)
+    assert np.array_equal(t0, nodes["val"][dleaf[:, 0]])
+
+
+def test_irregular_generator_shape(ta):
+    sn, tr = ta.capi.synth_sparse_forest(60, 32, min_depth=4, max_depth=24, leaf_prob=0.32, max_tree_nodes=65535, seed=44)
+    again, tr2 = ta.capi.synth_sparse_forest(60, 32, min_depth=4, max_depth=24, leaf_prob=0.32, max_tree_nodes=65535, seed=44)
+    assert sn.tobytes() == again.tobytes() and tr.tobytes() == tr2.tobytes()
+    sizes = np.diff(np.append(tr, sn.size))
+    assert sizes.min() >= 31 and sizes.max() <= 65535 and len(set(sizes.tolist())) > 10  # >= depth 4, irregular
+    bits = sn["bits"].view(np.uint32)
+    inner = (bits >> 31) == 0
+    assert ((bits[inner] & ((1 << 30) - 1)) < 32).all()
+    # depth of every tree by walking the links
+    for t in range(0, 60, 7):
+        lo = tr[t]
+        depth = {0: 0}
+        for i in range(sizes[t]):
+            if inner[lo + i]:
+                li = sn["left_idx"][lo + i]
+                depth[li] = depth[li + 1] = depth[i] + 1
+        assert 4 <= max(depth.values()) <= 24
+
+
+@pytest.mark.gpu
+def test_sparse_walk_on_gpu(ta):
+    import torch
+
+    assert torch.cuda.is_available()
+    cases = []
+    # (1) converted dense forest: must reproduce the dense prediction bit for bit
+    T, D, C, R = 23, 7, 40, 1500
+    nodes = ta.synth_forest(T, D, C, seed=5, leaf_prob=0.15)
+    sn, tr = ta.capi.dense_to_sparse(nodes, T, D)
+    data = ta.synth_data(R, C, seed=6, missing_prob=0.05, missing=MISSING, nan_prob=0.02)
+    dense_pred, _ = oracle.predict(nodes, T, D, data, MISSING)
+    cases.append((sn, tr, C, data, dense_pred))
+    # (2) irregular K5-like forest, small; (3) wide rows: the 64-row tile does not fit LDS -> features from global
+    for (nt, cols, rows, seed) in ((200, 64, 3000, 44), (30, 3072, 200, 45)):
+        sn2, tr2 = ta.capi.synth_sparse_forest(nt, cols, 4, 24, 0.32, 65535, seed)
+        d2 = ta.synth_data(rows, cols, seed=seed + 1, missing_prob=0.05, missing=MISSING, nan_prob=0.02)
+        cases.append((sn2, tr2, cols, d2, None))
+    for sn_, tr_, cols, data_, dense_expect in cases:
+        want, want_leaf = oracle.sparse_predict(sn_, tr_, data_, MISSING, want_leaf=True, threads=8)
+        if dense_expect is not None:
+            assert np.array_equal(want.view(np.uint32), dense_expect.view(np.uint32))
+        f = ta.capi.SparseForest(sn_, tr_, cols, missing=MISSING)
+        assert f.info().is_sparse == 1
+        x = torch.from_numpy(data_).cuda()
+        for strategy in (ta.STRATEGY_AUTO, ta.STRATEGY_DIRECT):
+            f.set_strategy(strategy)
+            leaf, sums = f.predict_leaf_idx(x)
+            raw = f.predict_raw(x)
+            f.check()
+            assert np.array_equal(leaf.cpu().numpy().view(np.uint32), want_leaf)
+            assert np.array_equal(sums.cpu().numpy().view(np.uint32), want.view(np.uint32))
+            assert np.array_equal(raw.cpu().numpy().view(np.uint32), want.view(np.uint32))
+        with pytest.raises(ta.TahoeError):
+            f.set_strategy(ta.STRATEGY_QRING)
+    # malformed forests are rejected (the reference would walk out of the arrays or spin)
+    bad = sn.copy()
+    first_inner = int(np.flatnonzero((bad["bits"].view(np.uint32) >> 31) == 0)[0])
+    bad["left_idx"][first_inner] = 0  # child link pointing backwards / at itself
+    with pytest.raises(ta.TahoeError) as e:
+        ta.capi.SparseForest(bad, tr, C)
+    assert e.value.status == 6
