@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""Runs BASELINE.json's five configurations once on cuda:0: parity against the CPU oracle (all rows for the small
+ones, a strided sample for the 1M-row ones) and kernel timing.  Writes gpurun_out/configs.json (copy the result to
+profiles/).  K3 is what bench.py measures; the others are parity cases with a timing for orientation."""
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import tahoe_amd as ta  # noqa: E402
+from oracle import oracle  # noqa: E402
+
+MISSING = -999.0
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def time_predict(forest, x, steps=5, warmup=2):
+    out = torch.empty(x.shape[0], dtype=torch.float32, device="cuda")
+    for _ in range(warmup):
+        forest.predict_raw(x, out)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        forest.predict_raw(x, out)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3, out
+
+
+def check_dense(forest, nodes, T, D, data, x, sample):
+    want, want_leaf = oracle.predict(nodes, T, D, data[sample], MISSING, want_leaf=True, threads=16)
+    leaf, sums = forest.predict_leaf_idx(x[torch.from_numpy(sample).cuda()].contiguous())
+    forest.check()
+    return bool(np.array_equal(bits(leaf.cpu().numpy()), want_leaf) and np.array_equal(bits(sums.cpu().numpy()), bits(want)))
+
+
+def main():
+    res = {}
+    # K1: SUSY-like through the text formats (C=18, 500 trees, depth 8, 10K rows)
+    T, D, C, R = 500, 8, 18, 10_000
+    nodes = ta.synth_forest(T, D, C, seed=11, leaf_prob=0.05)
+    data = ta.synth_data(R, C, seed=12, missing_prob=0.02, missing=MISSING)
+    with tempfile.TemporaryDirectory() as d:
+        ta.write_model(os.path.join(d, "m.txt"), nodes, T, D)
+        ta.write_data(os.path.join(d, "d.txt"), data, MISSING)
+        n2, T2, D2 = ta.load_model(os.path.join(d, "m.txt"))
+        x2, miss = ta.load_data(os.path.join(d, "d.txt"))
+    assert n2.tobytes() == nodes.tobytes() and x2.tobytes() == data.tobytes()
+    f = ta.Forest(n2, T2, D2, C, missing=miss)
+    x = torch.from_numpy(x2).cuda()
+    ms, _ = time_predict(f, x)
+    res["K1"] = {"shape": [T, D, C, R], "strategy": ta.STRATEGY_NAMES[f.get_strategy(R)], "ms": round(ms, 4),
+                 "samples_per_s": round(R / ms * 1e3), "parity_all_rows": check_dense(f, n2, T2, D2, x2, x, np.arange(R))}
+    # K2: SVHN-like width (C=3072, 500 trees, depth 8, 100K rows)
+    T, D, C, R = 500, 8, 3072, 100_000
+    nodes = ta.synth_forest(T, D, C, seed=21)
+    data = ta.synth_data(R, C, seed=22)
+    f = ta.Forest(nodes, T, D, C, missing=MISSING)
+    x = torch.from_numpy(data).cuda()
+    ms, _ = time_predict(f, x, steps=3, warmup=1)
+    res["K2"] = {"shape": [T, D, C, R], "strategy": ta.STRATEGY_NAMES[f.get_strategy(R)], "ms": round(ms, 3),
+                 "samples_per_s": round(R / ms * 1e3), "parity_sample_2000": check_dense(f, nodes, T, D, data, x, np.arange(0, R, 50))}
+    del x, data
+    # K3 / K4: 1M rows x 256 features; K4 = 8000 trees, also as 8 tree shards summed in rank order on this one GPU
+    C, R, D = 256, 1_000_000, 12
+    data = ta.synth_data(R, C, seed=43)
+    x = torch.from_numpy(data).cuda()
+    sample = np.unique(np.concatenate([np.arange(0, R, 2003), [R - 1]]))
+    for name, T in (("K3", 1000), ("K4", 8000)):
+        nodes = ta.synth_forest(T, D, C, seed=42)
+        f = ta.Forest(nodes, T, D, C, missing=MISSING)
+        ms, full = time_predict(f, x, steps=3, warmup=1)
+        entry = {"shape": [T, D, C, R], "strategy": ta.STRATEGY_NAMES[f.get_strategy(R)], "ms": round(ms, 3),
+                 "samples_per_s": round(R / ms * 1e3), "parity_sample_%d" % sample.size: check_dense(f, nodes, T, D, data, x, sample)}
+        if name == "K4":
+            per = ta.capi.tree_num_nodes(D)
+            total = torch.zeros(R, dtype=torch.float32, device="cuda")
+            shard_ms = []
+            for k in range(8):
+                lo, hi = T * k // 8, T * (k + 1) // 8
+                fs = ta.Forest(nodes[lo * per: hi * per], hi - lo, D, C, missing=MISSING)
+                m, part = time_predict(fs, x, steps=2, warmup=1)
+                shard_ms.append(m)
+                total += part  # what the all-reduce computes, in rank order
+                fs.close()
+            exact = oracle.predict_f64(nodes, T, D, data[sample], MISSING)
+            got = total.cpu().numpy()[sample]
+            entry["tree_shards_8"] = {"ms_per_shard_avg": round(float(np.mean(shard_ms)), 3),
+                                      "max_abs_err_vs_f64": float(np.max(np.abs(got - exact))),
+                                      "max_rel_err_vs_1gpu_f32": float(np.max(np.abs(got - full.cpu().numpy()[sample])
+                                                                              / np.maximum(np.abs(got), 1e-30)))}
+        res[name] = entry
+        f.close()
+    del x
+    # K5: irregular sparse forest (2000 trees, depth 4..24), 200K rows
+    T, C, R = 2000, 256, 200_000
+    sn, tr = ta.capi.synth_sparse_forest(T, C, 4, 24, 0.32, 65535, 44)
+    f = ta.capi.SparseForest(sn, tr, C, missing=MISSING)
+    x = torch.from_numpy(data[:R].copy()).cuda()
+    ms, _ = time_predict(f, x, steps=2, warmup=1)
+    sample = np.arange(0, R, 400)
+    want, want_leaf = oracle.sparse_predict(sn, tr, data[:R][sample], MISSING, want_leaf=True, threads=16)
+    leaf, sums = f.predict_leaf_idx(x[torch.from_numpy(sample).cuda()].contiguous())
+    f.check()
+    sizes = np.diff(np.append(tr, sn.size))
+    res["K5"] = {"shape": {"trees": T, "cols": C, "rows": R, "nodes": int(sn.size), "nodes_per_tree_mean": float(sizes.mean()),
+                           "nodes_per_tree_max": int(sizes.max())},
+                 "strategy": "sparse_" + ta.STRATEGY_NAMES[f.get_strategy(R)], "ms": round(ms, 3), "samples_per_s": round(R / ms * 1e3),
+                 "parity_sample_%d" % sample.size: bool(np.array_equal(bits(leaf.cpu().numpy()), want_leaf)
+                                                         and np.array_equal(bits(sums.cpu().numpy()), bits(want)))}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "configs.json"), "w") as fh:
+        json.dump(res, fh, indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
