@@ -188,6 +188,7 @@ typedef struct {
     int tileblock_lds_bytes; /* dynamic LDS of the TILEBLOCK kernel */
     int qring_walkers;       /* walker waves of the QRING kernel; 0 = strategy unavailable */
     int qring_lds_bytes;     /* dynamic LDS of the QRING kernel */
+    int qring_groups;        /* tree groups quantised separately (forests with > 32767 thresholds per feature) */
     int is_sparse;           /* 1: handle made by tahoe_sparse_forest_create (only the generic fields are set) */
     int ring_rows;           /* rows per TILERING tile: 64, 128, or 0 = strategy unavailable */
     int tilering_lds_bytes;  /* dynamic LDS of the TILERING kernel */

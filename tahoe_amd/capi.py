@@ -83,6 +83,7 @@ class ForestInfo(C.Structure):
         ("tileblock_lds_bytes", C.c_int),
         ("qring_walkers", C.c_int),
         ("qring_lds_bytes", C.c_int),
+        ("qring_groups", C.c_int),
         ("is_sparse", C.c_int),
         ("ring_rows", C.c_int),
         ("tilering_lds_bytes", C.c_int),

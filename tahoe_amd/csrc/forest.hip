@@ -1182,6 +1182,7 @@ tahoe_status tahoe_forest_get_info(const tahoe_forest *f, tahoe_forest_info *inf
     info->tileblock_lds_bytes = info->tile_rows ? (int)tileblock_lds_bytes(f, info->tile_rows) : 0;
     info->qring_walkers = qring_walkers(f);
     info->qring_lds_bytes = (int)qring_lds_bytes(f);
+    info->qring_groups = qring_groups(f);
     info->ring_rows = tilering_rows(f);
     info->tilering_lds_bytes = info->ring_rows ? (int)tilering_lds_bytes(f, info->ring_rows) : 0;
     return TAHOE_OK;

@@ -30,24 +30,33 @@
 #include <cstring>
 #include <new>
 #include <type_traits>
+#include <vector>
 
 #include "forest_internal.h"
 
+// One group of consecutive trees with its own quantisation (a forest whose features see more than 32767
+// distinct thresholds is cut into groups that each stay below; the running float32 sums are chained from
+// group to group, so the result is still the single sequential sum over all trees).
+struct tahoe_qgroup {
+    int tree_lo = 0, num_trees = 0;
+    int max_table = 0;            // floats of the largest per-feature search tree (2^p)
+    int pair_lds_floats = 0;      // LDS floats of quantize_pair_kernel; 0 = odd num_cols, single-feature form
+    float *tables = nullptr;      // concatenated search trees
+    int *offsets = nullptr;       // [cols + 1]
+    uint32_t *top = nullptr;      // [T_g][top_stride]
+    uint4 *blocks = nullptr;      // [T_g][2^(De-2)][2]
+    uint32_t *qinner = nullptr;   // [T_g][2^De - 1] (only when have_mid)
+};
+
 struct tahoe_qstate {
     int top_levels = 0;
-    int max_table = 0;            // floats of the largest per-feature search tree (2^p)
     bool have_mid = false;        // De - 2 > top_levels: heap of quantised nodes for the middle levels
-    float *tables = nullptr;      // concatenated tab_f
-    int *offsets = nullptr;       // [cols + 1]
-    uint32_t *top = nullptr;      // [T][2^L]
-    uint4 *blocks = nullptr;      // [T][2^(De-2)][2]
-    uint32_t *qinner = nullptr;   // [T][2^De - 1] (only when have_mid)
-    uint16_t *xq = nullptr;       // workspace: quantised tiles
-    size_t xq_rows = 0;           // rows the workspace holds
     int top_stride = 0;           // u32 entries per tree in `top` (>= 4)
+    std::vector<tahoe_qgroup> groups;
+    uint16_t *xq = nullptr;       // workspace: quantised tiles (re-used by every group)
+    size_t xq_rows = 0;           // rows the workspace holds
     uint32_t *chunk_flags = nullptr;  // workspace: per kQuantRowsPerBlock rows, "a missing value was seen"
     size_t n_chunk_flags = 0;
-    int pair_lds_floats = 0;      // LDS floats of quantize_pair_kernel; 0 = odd num_cols, single-feature form
 };
 
 namespace tahoe {
@@ -291,7 +300,8 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
     qring_kernel(const uint16_t *__restrict__ xq, const uint32_t *__restrict__ top, const uint4 *__restrict__ blocks,
                  const uint32_t *__restrict__ qinner, const uint32_t *__restrict__ leaf_orig, float *__restrict__ sums,
                  uint32_t *__restrict__ leaf_out, size_t rows, int cols, int num_trees, int depth, int top_levels,
-                 int top_stride, const uint32_t *__restrict__ chunk_flags, int *__restrict__ error_flag)
+                 int top_stride, const uint32_t *__restrict__ chunk_flags, int *__restrict__ error_flag,
+                 const float *__restrict__ sums_in, int tree_base, int total_trees)
 {
     constexpr int K = kQRows / 64;  // two 64-row chains per walker lane
     constexpr int NT = (NWALK + 1) * 64;
@@ -322,9 +332,12 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
     if (wave == NWALK) {
         // ================= consumer: ordered accumulation =================
         __syncthreads();
-        float sum[K];
+        float sum[K];  // continues the running sums of the previous tree group (sums_in may alias sums)
 #pragma unroll
-        for (int k = 0; k < K; ++k) sum[k] = 0.0f;
+        for (int k = 0; k < K; ++k) {
+            const size_t irow = row0 + k * 64 + lane;
+            sum[k] = (sums_in && irow < rows) ? sums_in[irow] : 0.0f;
+        }
         bool dead = false;
         for (int t0 = 0; t0 < num_trees && !dead; t0 += kQBatch) {
             const int nb = min(kQBatch, num_trees - t0);
@@ -412,7 +425,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                 if (WRITE_LEAF) {
                     const size_t row = row0 + k * 64 + lane;
                     if (row < rows)
-                        leaf_out[row * (size_t)num_trees + t] =
+                        leaf_out[row * (size_t)total_trees + tree_base + t] =
                             leaf_orig[(size_t)t * ((size_t)n_blocks * 4) + (size_t)bs[k] * 4 + 2 * (c0 ? 1 : 0) + (c1 ? 1 : 0)];
                 }
             }
@@ -552,30 +565,35 @@ static hipError_t q_allow(long long lds)
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
-tahoe_status qring_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner, const std::vector<unsigned char> &h_real,
-                         const std::vector<float> &h_leaf)
+// Builds one tree group [lo, hi).  Returns TAHOE_OK with *too_many = the largest per-feature count when that
+// exceeds the limit (nothing is allocated then).
+static tahoe_status build_group(tahoe_forest *f, const std::vector<InnerNode> &h_inner, const std::vector<unsigned char> &h_real,
+                                const std::vector<float> &h_leaf, size_t lo, size_t hi, tahoe_qgroup &g, int *too_many)
 {
+    tahoe_qstate *q = f->q;
     const int cols = f->p.num_cols;
-    const size_t T = (size_t)f->p.num_trees;
-    if (cols < 1 || cols > 32767 || T == 0) return TAHOE_OK;  // strategy simply unavailable
+    const size_t n_inner = f->n_inner, n_leaf = f->n_leaf;
+    *too_many = 0;
     // ---- per-feature tables of distinct thresholds ----
     std::vector<std::vector<float>> tab((size_t)cols);
-    for (size_t i = 0; i < h_inner.size(); ++i) {
+    for (size_t i = lo * n_inner; i < hi * n_inner; ++i) {
         if (!h_real[i] || std::isnan(h_inner[i].thr)) continue;
         tab[h_inner[i].meta & 0x7fffffffu].push_back(h_inner[i].thr);
     }
-    std::vector<int> offsets((size_t)cols + 1, 0);
-    int max_table = 0;
+    int max_count = 0;
     for (int c = 0; c < cols; ++c) {
         auto &v = tab[c];
         std::sort(v.begin(), v.end());                       // float order; -0.0f and 0.0f compare equal
         v.erase(std::unique(v.begin(), v.end()), v.end());   // ... and collapse into one entry
-        max_table = std::max(max_table, (int)v.size());
-        offsets[c + 1] = offsets[c] + (int)v.size();
+        max_count = std::max(max_count, (int)v.size());
     }
-    if (max_table > kQMaxTable) return TAHOE_OK;  // unavailable: the float32 strategies serve this forest
+    if (max_count > kQMaxTable) {
+        *too_many = max_count;
+        return TAHOE_OK;
+    }
     // device form of each table: perfect BST in level order, 1-based, 2^p entries, NaN padding (compares
     // false, i.e. "greater than every x"); entry 0 unused
+    std::vector<int> offsets((size_t)cols + 1, 0);
     std::vector<float> tables;
     int max_size = 1;
     for (int c = 0; c < cols; ++c) {
@@ -586,8 +604,7 @@ tahoe_status qring_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner,
         offsets[c] = (int)tables.size();
         const size_t at = tables.size();
         tables.resize(at + (size_t)size, std::nanf(""));
-        // in-order walk of the implicit tree assigns the sorted values
-        size_t next = 0;
+        size_t next = 0;  // in-order walk of the implicit tree assigns the sorted values
         std::vector<int> stack;
         int k = 1;
         while ((k < size) || !stack.empty()) {
@@ -616,25 +633,20 @@ tahoe_status qring_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner,
         }
         return code | (fid << 16) | (dl << 31);
     };
-    tahoe_qstate *q = new (std::nothrow) tahoe_qstate();
-    if (!q) return fail(TAHOE_ERR_NO_MEMORY, "qring_build");
-    f->q = q;
-    q->max_table = max_size;  // LDS floats the quantise kernel needs
-    const int De = f->depth;
-    q->top_levels = f->top_levels;
-    q->have_mid = De - 2 > q->top_levels;
-    const size_t n_inner = f->n_inner, n_leaf = f->n_leaf;
+    const size_t Tg = hi - lo;
+    g.tree_lo = (int)lo;
+    g.num_trees = (int)Tg;
+    g.max_table = max_size;
     const size_t top_n = (size_t)1 << q->top_levels;  // entries per tree (entry 0 unused)
-    const size_t n_blocks = (size_t)1 << (De - 2);
+    const size_t top_stride = (size_t)q->top_stride;
+    const size_t n_blocks = (size_t)1 << (f->depth - 2);
     const size_t first = n_blocks - 1;
-    std::vector<uint32_t> h_top(T * std::max<size_t>(top_n, 4), 0u);  // >= 16 bytes per tree
-    std::vector<uint4> h_blocks(T * n_blocks * 2);
-    std::vector<uint32_t> h_qinner(q->have_mid ? T * n_inner : 0);
-    const size_t top_stride = std::max<size_t>(top_n, 4);
-    q->top_stride = (int)top_stride;
-    for (size_t t = 0; t < T; ++t) {
-        const InnerNode *in = &h_inner[t * n_inner];
-        const unsigned char *re = &h_real[t * n_inner];
+    std::vector<uint32_t> h_top(Tg * top_stride, 0u);
+    std::vector<uint4> h_blocks(Tg * n_blocks * 2);
+    std::vector<uint32_t> h_qinner(q->have_mid ? Tg * n_inner : 0);
+    for (size_t t = 0; t < Tg; ++t) {
+        const InnerNode *in = &h_inner[(lo + t) * n_inner];
+        const unsigned char *re = &h_real[(lo + t) * n_inner];
         for (size_t i = 0; i + 1 < top_n; ++i) h_top[t * top_stride + i + 1] = encode(in[i], re[i] != 0);
         if (q->have_mid)
             for (size_t i = 0; i < n_inner; ++i) h_qinner[t * n_inner + i] = encode(in[i], re[i] != 0);
@@ -645,7 +657,7 @@ tahoe_status qring_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner,
             a.y = encode(in[l], re[l] != 0);
             a.z = encode(in[rr], re[rr] != 0);
             a.w = 0u;
-            const float *lv = &h_leaf[t * n_leaf + 4 * b];
+            const float *lv = &h_leaf[(lo + t) * n_leaf + 4 * b];
             memcpy(&v.x, &lv[0], 4);
             memcpy(&v.y, &lv[1], 4);
             memcpy(&v.z, &lv[2], 4);
@@ -654,22 +666,8 @@ tahoe_status qring_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner,
             h_blocks[(t * n_blocks + b) * 2 + 1] = v;
         }
     }
-    hipError_t e;
-    auto bad = [&](const char *what) { return fail(TAHOE_ERR_HIP, "qring_build: %s failed: %s", what, hipGetErrorString(e)); };
-    if ((e = q_upload(&q->tables, tables.data(), tables.size(), &f->device_bytes)) != hipSuccess) return bad("tables");
-    if ((e = q_upload(&q->offsets, offsets.data(), offsets.size(), &f->device_bytes)) != hipSuccess) return bad("offsets");
-    if ((e = q_upload(&q->top, h_top.data(), h_top.size(), &f->device_bytes)) != hipSuccess) return bad("top");
-    if ((e = q_upload(&q->blocks, h_blocks.data(), h_blocks.size(), &f->device_bytes)) != hipSuccess) return bad("blocks");
-    if (q->have_mid &&
-        (e = q_upload(&q->qinner, h_qinner.data(), h_qinner.size(), &f->device_bytes)) != hipSuccess)
-        return bad("qinner");
-    // kernels that need more than 64 KiB of dynamic LDS
-    if (qring_lds_for(f, 15) <= f->lds_limit && (e = q_allow<15>(qring_lds_for(f, 15))) != hipSuccess) return bad("attr15");
-    if (qring_lds_for(f, 12) <= f->lds_limit && (e = q_allow<12>(qring_lds_for(f, 12))) != hipSuccess) return bad("attr12");
-    if (qring_lds_for(f, 8) <= f->lds_limit && (e = q_allow<8>(qring_lds_for(f, 8))) != hipSuccess) return bad("attr8");
-    if (qring_lds_for(f, 4) <= f->lds_limit && (e = q_allow<4>(qring_lds_for(f, 4))) != hipSuccess) return bad("attr4");
     // quantise kernel form: feature pairs with both trees resident when they fit, else one feature per WG
-    q->pair_lds_floats = 0;
+    g.pair_lds_floats = 0;
     if (cols % 2 == 0) {
         const int budget = 36 * 1024;  // floats: 144 KiB of LDS
         int need = 0;
@@ -677,15 +675,80 @@ tahoe_status qring_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner,
             const int s0 = offsets[c + 1] - offsets[c], s1 = offsets[c + 2] - offsets[c + 1];
             need = std::max(need, s0 + s1 <= budget ? s0 + s1 : std::max(s0, s1));
         }
-        q->pair_lds_floats = std::max(need, 1);
-        if (q->pair_lds_floats * 4 > 64 * 1024 &&
-            (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&quantize_pair_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, q->pair_lds_floats * 4)) != hipSuccess)
-            return bad("attr(quantize_pair)");
+        g.pair_lds_floats = std::max(need, 1);
     }
-    if (max_size * 4 > 64 * 1024 &&
+    hipError_t e;
+    auto bad = [&](const char *what) { return fail(TAHOE_ERR_HIP, "qring_build: %s failed: %s", what, hipGetErrorString(e)); };
+    if ((e = q_upload(&g.tables, tables.data(), tables.size(), &f->device_bytes)) != hipSuccess) return bad("tables");
+    if ((e = q_upload(&g.offsets, offsets.data(), offsets.size(), &f->device_bytes)) != hipSuccess) return bad("offsets");
+    if ((e = q_upload(&g.top, h_top.data(), h_top.size(), &f->device_bytes)) != hipSuccess) return bad("top");
+    if ((e = q_upload(&g.blocks, h_blocks.data(), h_blocks.size(), &f->device_bytes)) != hipSuccess) return bad("blocks");
+    if (q->have_mid && (e = q_upload(&g.qinner, h_qinner.data(), h_qinner.size(), &f->device_bytes)) != hipSuccess)
+        return bad("qinner");
+    return TAHOE_OK;
+}
+
+static void free_group(tahoe_qgroup &g)
+{
+    for (void *p : {(void *)g.tables, (void *)g.offsets, (void *)g.top, (void *)g.blocks, (void *)g.qinner})
+        if (p) (void)hipFree(p);
+    g = tahoe_qgroup();
+}
+
+tahoe_status qring_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner, const std::vector<unsigned char> &h_real,
+                         const std::vector<float> &h_leaf)
+{
+    const int cols = f->p.num_cols;
+    const size_t T = (size_t)f->p.num_trees;
+    if (cols < 1 || cols > 32767 || T == 0) return TAHOE_OK;  // strategy simply unavailable
+    tahoe_qstate *q = new (std::nothrow) tahoe_qstate();
+    if (!q) return fail(TAHOE_ERR_NO_MEMORY, "qring_build");
+    f->q = q;
+    q->top_levels = f->top_levels;
+    q->have_mid = f->depth - 2 > q->top_levels;
+    q->top_stride = (int)std::max<size_t>((size_t)1 << q->top_levels, 4);  // >= 16 bytes per tree
+    // ---- cut the forest into tree groups whose features each see <= kQMaxTable distinct thresholds ----
+    size_t lo = 0, gsize = T;
+    while (lo < T) {
+        size_t hi = std::min(T, lo + gsize);
+        tahoe_qgroup g;
+        for (;;) {
+            int too_many = 0;
+            const tahoe_status s = build_group(f, h_inner, h_real, h_leaf, lo, hi, g, &too_many);
+            if (s != TAHOE_OK) {
+                free_group(g);
+                return s;  // create() destroys the handle, which frees the finished groups
+            }
+            if (too_many == 0) break;
+            if (hi - lo == 1) {  // a single tree exceeds the limit: the strategy is unavailable
+                qring_destroy(f);
+                return TAHOE_OK;
+            }
+            gsize = std::max<size_t>(1, (size_t)((double)(hi - lo) * kQMaxTable / too_many * 0.9));
+            hi = lo + gsize;
+        }
+        q->groups.push_back(g);
+        lo = hi;
+    }
+    // kernels that need more than 64 KiB of dynamic LDS
+    hipError_t e;
+    auto bad = [&](const char *what) { return fail(TAHOE_ERR_HIP, "qring_build: %s failed: %s", what, hipGetErrorString(e)); };
+    if (qring_lds_for(f, 15) <= f->lds_limit && (e = q_allow<15>(qring_lds_for(f, 15))) != hipSuccess) return bad("attr15");
+    if (qring_lds_for(f, 12) <= f->lds_limit && (e = q_allow<12>(qring_lds_for(f, 12))) != hipSuccess) return bad("attr12");
+    if (qring_lds_for(f, 8) <= f->lds_limit && (e = q_allow<8>(qring_lds_for(f, 8))) != hipSuccess) return bad("attr8");
+    if (qring_lds_for(f, 4) <= f->lds_limit && (e = q_allow<4>(qring_lds_for(f, 4))) != hipSuccess) return bad("attr4");
+    int pair_max = 0, single_max = 1;
+    for (const tahoe_qgroup &g : q->groups) {
+        pair_max = std::max(pair_max, g.pair_lds_floats);
+        single_max = std::max(single_max, g.max_table);
+    }
+    if (pair_max * 4 > 64 * 1024 &&
+        (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&quantize_pair_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, pair_max * 4)) != hipSuccess)
+        return bad("attr(quantize_pair)");
+    if (single_max * 4 > 64 * 1024 &&
         (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&quantize_kernel<1>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, max_size * 4)) != hipSuccess)
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, single_max * 4)) != hipSuccess)
         return bad("attr(quantize)");
     return TAHOE_OK;
 }
@@ -694,12 +757,14 @@ void qring_destroy(tahoe_forest *f)
 {
     tahoe_qstate *q = f->q;
     if (!q) return;
-    for (void *p : {(void *)q->tables, (void *)q->offsets, (void *)q->top, (void *)q->blocks, (void *)q->qinner,
-                    (void *)q->xq, (void *)q->chunk_flags})
-        if (p) (void)hipFree(p);
+    for (tahoe_qgroup &g : q->groups) free_group(g);
+    if (q->xq) (void)hipFree(q->xq);
+    if (q->chunk_flags) (void)hipFree(q->chunk_flags);
     delete q;
     f->q = nullptr;
 }
+
+int qring_groups(const tahoe_forest *f) { return f->q ? (int)f->q->groups.size() : 0; }
 
 // The quantised copy of the batch lives in a grow-only workspace owned by the handle.
 tahoe_status qring_reserve(tahoe_forest *f, size_t rows)
@@ -726,19 +791,21 @@ tahoe_status qring_reserve(tahoe_forest *f, size_t rows)
 }
 
 template <int NWALK>
-static void q_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, size_t rows, hipStream_t stream)
+static void q_launch(tahoe_forest *f, const tahoe_qgroup &g, float *sums, const float *sums_in, uint32_t *leaf_out,
+                     size_t rows, hipStream_t stream)
 {
     tahoe_qstate *q = f->q;
     const unsigned grid = (unsigned)((rows + kQRows - 1) / kQRows);
     const int lds = (int)qring_lds_for(f, NWALK);
+    const uint32_t *leaf_orig = f->leaf_orig + (size_t)g.tree_lo * f->n_leaf;
     if (leaf_out)
-        hipLaunchKernelGGL((qring_kernel<NWALK, true>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, q->top,
-                           q->blocks, q->qinner, f->leaf_orig, sums, leaf_out, rows, f->p.num_cols, f->p.num_trees,
-                           f->depth, q->top_levels, q->top_stride, q->chunk_flags, f->error_flag);
+        hipLaunchKernelGGL((qring_kernel<NWALK, true>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, g.top,
+                           g.blocks, g.qinner, leaf_orig, sums, leaf_out, rows, f->p.num_cols, g.num_trees, f->depth,
+                           q->top_levels, q->top_stride, q->chunk_flags, f->error_flag, sums_in, g.tree_lo, f->p.num_trees);
     else
-        hipLaunchKernelGGL((qring_kernel<NWALK, false>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, q->top,
-                           q->blocks, q->qinner, f->leaf_orig, sums, leaf_out, rows, f->p.num_cols, f->p.num_trees,
-                           f->depth, q->top_levels, q->top_stride, q->chunk_flags, f->error_flag);
+        hipLaunchKernelGGL((qring_kernel<NWALK, false>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, g.top,
+                           g.blocks, g.qinner, leaf_orig, sums, leaf_out, rows, f->p.num_cols, g.num_trees, f->depth,
+                           q->top_levels, q->top_stride, q->chunk_flags, f->error_flag, sums_in, g.tree_lo, f->p.num_trees);
 }
 
 tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, const float *data, size_t rows,
@@ -748,32 +815,37 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
     const int nwalk = qring_walkers(f);
     if (!q || nwalk == 0)
         return fail(TAHOE_ERR_UNSUPPORTED,
-                    "QRING needs <= %d distinct thresholds per feature, num_cols <= 32767 and a 128-row u16 tile in LDS",
-                    kQMaxTable);
+                    "QRING needs <= %d distinct thresholds per feature within one tree, num_cols <= 32767 and a 128-row "
+                    "u16 tile in LDS", kQMaxTable);
     tahoe_status s = qring_reserve(f, rows);  // no-op unless this batch is larger than any before
     if (s != TAHOE_OK) return s;
     const size_t chunks = (rows + kQuantRowsPerBlock - 1) / kQuantRowsPerBlock;
-    TAHOE_HIP_TRY(hipMemsetAsync(q->chunk_flags, 0, q->n_chunk_flags * sizeof(uint32_t), stream));
-    const bool pair_ok = q->pair_lds_floats > 0 && (reinterpret_cast<uintptr_t>(data) % 8) == 0;  // float2 loads
-    const size_t qgrid = chunks * (size_t)(pair_ok ? f->p.num_cols / 2 : f->p.num_cols);
-    if (qgrid > 0x7fffffffu) return fail(TAHOE_ERR_INVALID_ARG, "too many rows x cols for one launch");
-    if (pair_ok)
-        hipLaunchKernelGGL(quantize_pair_kernel, dim3((unsigned)qgrid), dim3(kQuantPairThreads),
-                           (size_t)q->pair_lds_floats * 4, stream, data, q->tables, q->offsets, q->xq, q->chunk_flags, rows,
-                           f->p.num_cols, f->p.missing, q->pair_lds_floats);
-    else
-        hipLaunchKernelGGL(quantize_kernel<1>, dim3((unsigned)qgrid), dim3(kQuantThreads), (size_t)std::max(q->max_table, 1) * 4,
-                           stream, data, q->tables, q->offsets, q->xq, q->chunk_flags, rows, f->p.num_cols, f->p.missing,
-                           std::max(q->max_table, 1));
-    TAHOE_HIP_TRY(hipGetLastError());
-    if (mid_event) TAHOE_HIP_TRY(hipEventRecord(mid_event, stream));
-    switch (nwalk) {
-        case 15: q_launch<15>(f, sums, leaf_out, rows, stream); break;
-        case 12: q_launch<12>(f, sums, leaf_out, rows, stream); break;
-        case 8: q_launch<8>(f, sums, leaf_out, rows, stream); break;
-        default: q_launch<4>(f, sums, leaf_out, rows, stream); break;
+    bool first = true;
+    for (const tahoe_qgroup &g : q->groups) {  // stream order: quantise for the group, walk the group, next group
+        TAHOE_HIP_TRY(hipMemsetAsync(q->chunk_flags, 0, q->n_chunk_flags * sizeof(uint32_t), stream));
+        const bool pair_ok = g.pair_lds_floats > 0 && (reinterpret_cast<uintptr_t>(data) % 8) == 0;  // float2 loads
+        const size_t qgrid = chunks * (size_t)(pair_ok ? f->p.num_cols / 2 : f->p.num_cols);
+        if (qgrid > 0x7fffffffu) return fail(TAHOE_ERR_INVALID_ARG, "too many rows x cols for one launch");
+        if (pair_ok)
+            hipLaunchKernelGGL(quantize_pair_kernel, dim3((unsigned)qgrid), dim3(kQuantPairThreads),
+                               (size_t)g.pair_lds_floats * 4, stream, data, g.tables, g.offsets, q->xq, q->chunk_flags, rows,
+                               f->p.num_cols, f->p.missing, g.pair_lds_floats);
+        else
+            hipLaunchKernelGGL(quantize_kernel<1>, dim3((unsigned)qgrid), dim3(kQuantThreads), (size_t)std::max(g.max_table, 1) * 4,
+                               stream, data, g.tables, g.offsets, q->xq, q->chunk_flags, rows, f->p.num_cols, f->p.missing,
+                               std::max(g.max_table, 1));
+        TAHOE_HIP_TRY(hipGetLastError());
+        if (first && mid_event) TAHOE_HIP_TRY(hipEventRecord(mid_event, stream));  // splits pre-pass / walk for 1 group
+        const float *sums_in = first ? nullptr : sums;  // later groups continue the running float32 sums
+        switch (nwalk) {
+            case 15: q_launch<15>(f, g, sums, sums_in, leaf_out, rows, stream); break;
+            case 12: q_launch<12>(f, g, sums, sums_in, leaf_out, rows, stream); break;
+            case 8: q_launch<8>(f, g, sums, sums_in, leaf_out, rows, stream); break;
+            default: q_launch<4>(f, g, sums, sums_in, leaf_out, rows, stream); break;
+        }
+        TAHOE_HIP_TRY(hipGetLastError());
+        first = false;
     }
-    TAHOE_HIP_TRY(hipGetLastError());
     return TAHOE_OK;
 }
 

@@ -273,13 +273,28 @@ def test_quantised_threshold_edge_values(env):
     assert f.info().qring_walkers > 0 and f.get_strategy(R) == ta.STRATEGY_QRING
 
 
-def test_qring_unavailable_with_too_many_thresholds(env):
-    """More than 32767 distinct thresholds on one feature: the quantised strategy steps aside, AUTO falls back
-    to a float32 strategy, results unchanged."""
+def test_qring_tree_groups_and_unavailable(env):
+    """A forest whose features see more than 32767 distinct thresholds is quantised in groups of consecutive
+    trees; the running float32 sums are chained through the groups, so sums and leaf indices stay bit-exact.
+    A single tree that alone exceeds the limit makes the strategy step aside (AUTO falls back to float32)."""
     ta, oracle, torch = env
-    T, D, C, R = 3, 15, 1, 300  # 3 x 32767 inner nodes, all on feature 0, all distinct
+    T, D, C, R = 5, 15, 1, 300  # 32767 inner nodes per tree, all on feature 0, all distinct -> one tree per group
     nodes = ta.synth_forest(T, D, C, seed=41)
     data = ta.synth_data(R, C, seed=42, missing_prob=0.05, missing=MISSING)
+    f = ta.Forest(nodes, T, D, C, missing=MISSING)
+    assert f.info().qring_walkers > 0 and f.info().qring_groups == T
+    run_case(env, nodes, T, D, C, data)
+    # a few hundred trees per group
+    T, D, C, R = 700, 8, 4, 500
+    nodes = ta.synth_forest(T, D, C, seed=43)
+    data = ta.synth_data(R, C, seed=44, missing_prob=0.05, missing=MISSING)
+    f = ta.Forest(nodes, T, D, C, missing=MISSING)
+    assert 2 <= f.info().qring_groups <= 4 and f.get_strategy(R) == ta.STRATEGY_QRING
+    run_case(env, nodes, T, D, C, data, strategies=[ta.STRATEGY_QRING, ta.STRATEGY_TILERING])
+    # one tree with 65535 distinct thresholds on one feature: unavailable
+    T, D, C, R = 2, 16, 1, 100
+    nodes = ta.synth_forest(T, D, C, seed=45)
+    data = ta.synth_data(R, C, seed=46)
     f = ta.Forest(nodes, T, D, C, missing=MISSING)
     assert f.info().qring_walkers == 0
     with pytest.raises(ta.TahoeError) as e:
