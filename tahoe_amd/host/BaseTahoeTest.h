@@ -13,7 +13,7 @@
 // compare each against the CPU result with the reference's absolute 1e-3 tolerance (compare_GPU,
 // cuda_base.h:98-111) and return the 1-based index of the fastest strategy plus speedup = baseline / best.
 //   baseline ("FIL (baseline)")  = TAHOE_STRATEGY_DIRECT
-//   strategy 1..4               = DIRECT, ROWTILE, TILEBLOCK, TILERING;  5 = reserved (never suitable)
+//   strategy 1..5               = DIRECT, ROWTILE, TILEBLOCK, TILERING, QRING (the library's numbering)
 #ifndef TAHOE_AMD_BASETAHOETEST_H
 #define TAHOE_AMD_BASETAHOETEST_H
 
@@ -266,9 +266,9 @@ class BaseTahoeTest {
     void predict_on_gpu_strategies(float *acc)
     {
         static const int order[5] = {TAHOE_STRATEGY_DIRECT, TAHOE_STRATEGY_ROWTILE, TAHOE_STRATEGY_TILEBLOCK,
-                                     TAHOE_STRATEGY_TILERING, -1};
+                                     TAHOE_STRATEGY_TILERING, TAHOE_STRATEGY_QRING};
         for (int loop = 0; loop <= 4; ++loop) {
-            if (order[loop] < 0 || tahoe_forest_set_strategy(forest, order[loop]) != TAHOE_OK) {
+            if (tahoe_forest_set_strategy(forest, order[loop]) != TAHOE_OK) {
                 acc[loop] = FLT_MAX;
                 printf("Strategy %d is not suitable for this case.\n", loop + 1);
                 continue;

@@ -16,7 +16,7 @@ int main(int argc, char *argv[])
     BaseTahoeTest *pTest = new BaseTahoeTest(argv[1], argv[2]);
     float speedup = 0.0f;
     const int best_by_run = pTest->SetUp(speedup);
-    // SetUp numbers strategies 1..4 = DIRECT, ROWTILE, TILEBLOCK, TILERING, which are the library's 1..4
+    // SetUp numbers strategies 1..5 = DIRECT, ROWTILE, TILEBLOCK, TILERING, QRING, which are the library's 1..5
     std::cout << "Performance model choose #" << pTest->auto_strategy << " strategy." << std::endl;
     if (pTest->auto_strategy == best_by_run)
         std::cout << "Performance model predicts correctly" << std::endl;
