@@ -11,8 +11,11 @@
 //   node      u32: threshold code (1..n_f; 0xFFFF for a NaN threshold: never >=) | fid << 16 | def_left << 31
 //   top       [t][2^L] u32, 1-based heap positions (children of i = the aligned pair 2i, 2i+1), L <= 10
 //   block     [t][2^(De-2)] 32 B = {node0, node1, node2, 0} {leaf0..3 f32}: last two levels + leaves
-// Requires n_f <= 32767 for every feature (the per-feature table must fit LDS in the quantise kernel)
-// and num_cols <= 32767; otherwise the strategy is unavailable and the float32 strategies serve.
+// Requires num_cols <= 32767 and at most 32767 distinct thresholds per feature within a tree group (the
+// per-feature search tree must fit LDS in the quantise kernel; larger forests are cut into groups of
+// consecutive trees, see tahoe_qgroup); otherwise the strategy is unavailable and float32 strategies serve.
+// Rows too wide for an LDS tile (num_cols > ~550) use the GX form: same kernel, feature codes read from the
+// quantised tile in L2 instead of LDS.
 //
 // Per predict: (1) quantize_kernel turns the row-major float32 batch into 128-row tiles
 // xq[tile][fid][128] u16 (rows permuted inside a column so that lane = row reads are bank-conflict
@@ -284,18 +287,25 @@ __device__ __forceinline__ uint32_t q_descend(uint32_t i, uint64_t right_mask)
 // feature column 0 (tile base + position); a column is 256 bytes.  The address is formed as an LDS
 // (address-space 3) integer, fid * 256 + posb: v_bfe + v_lshl_add, two VALU.  (Going through the generic
 // `tile` pointer costs a third: hipcc adds the LDS base, a link-time 0, with its own v_add.)
+// LDSX = false ("GX" form, for rows too wide for an LDS tile): the same 256-byte columns are read straight from
+// the quantised tile in global memory (L2-resident: one 128-row tile of 3072 columns is 768 KiB); `gx` = the
+// tile's base, posb = byte position inside a column.
 typedef const uint16_t __attribute__((address_space(3))) *lds_u16_ptr;
-__device__ __forceinline__ uint32_t q_xread(const uint16_t * /*tile*/, uint32_t node, uint32_t posb)
+template <bool LDSX>
+__device__ __forceinline__ uint32_t q_xread(const unsigned char *gx, uint32_t node, uint32_t posb)
 {
-    uint32_t addr;  // asm: hipcc re-canonicalises the C form into shift + and + add
-    asm("v_bfe_u32 %0, %1, 16, 15\n\tv_lshl_add_u32 %0, %0, 8, %2" : "=&v"(addr) : "v"(node), "v"(posb));
-    return *reinterpret_cast<lds_u16_ptr>(addr);
+    if (LDSX) {
+        uint32_t addr;  // asm: hipcc re-canonicalises the C form into shift + and + add
+        asm("v_bfe_u32 %0, %1, 16, 15\n\tv_lshl_add_u32 %0, %0, 8, %2" : "=&v"(addr) : "v"(node), "v"(posb));
+        return *reinterpret_cast<lds_u16_ptr>(addr);
+    }
+    return *reinterpret_cast<const uint16_t *>(gx + (((node >> 16) & 0x7fffu) << 8) + posb);
 }
 
 // ------------------------------------------------------------------------------------------------
 // (2) the walk.  Dynamic LDS: tile [cols][128] u16 | NWALK slots of (4 << L) bytes | ring [16][128] f32 |
 // ready[16] | consumed.
-template <int NWALK, bool WRITE_LEAF>
+template <int NWALK, bool WRITE_LEAF, bool LDSX>
 __global__ void __launch_bounds__((NWALK + 1) * 64)
     qring_kernel(const uint16_t *__restrict__ xq, const uint32_t *__restrict__ top, const uint4 *__restrict__ blocks,
                  const uint32_t *__restrict__ qinner, const uint32_t *__restrict__ leaf_orig, float *__restrict__ sums,
@@ -311,8 +321,9 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int slot_bytes = kQSlotBytes;  // fixed 4 KiB slot (2^10 u32): no size-dependent branches in the loop
 
-    uint16_t *tile = reinterpret_cast<uint16_t *>(smem);
-    unsigned char *slots = smem + (size_t)cols * kQRows * sizeof(uint16_t);
+    uint16_t *tile = reinterpret_cast<uint16_t *>(smem);  // LDSX only
+    unsigned char *slots = smem + (LDSX ? (size_t)cols * kQRows * sizeof(uint16_t) : 0);
+    const unsigned char *gx = reinterpret_cast<const unsigned char *>(xq + (size_t)blockIdx.x * ((size_t)cols * kQRows));
     float *ring_vals = reinterpret_cast<float *>(slots + (size_t)NWALK * slot_bytes);
     uint32_t *ring_ready = reinterpret_cast<uint32_t *>(ring_vals + kQRing * kQRows);
     uint32_t *consumed = ring_ready + kQRing;
@@ -320,7 +331,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
     const size_t row0 = (size_t)blockIdx.x * kQRows;
 
     // ---- stage the quantised tile (already in LDS order): straight 16-byte copies ----
-    {
+    if (LDSX) {
         const uint4 *src = reinterpret_cast<const uint4 *>(xq + (size_t)blockIdx.x * ((size_t)cols * kQRows));
         uint4 *dst = reinterpret_cast<uint4 *>(tile);
         const int n16 = cols * kQRows * 2 / 16;
@@ -406,7 +417,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
         uint32_t pos[K];  // byte position of this lane's row inside a 256-byte feature column, per chain
     #pragma unroll
         for (int k = 0; k < K; ++k)  // low 32 bits of a generic LDS pointer = the LDS byte address
-            pos[k] = (uint32_t)reinterpret_cast<uintptr_t>(tile) + 2u * (uint32_t)qrow_pos(k * 64 + lane);
+            pos[k] = (LDSX ? (uint32_t)reinterpret_cast<uintptr_t>(tile) : 0u) + 2u * (uint32_t)qrow_pos(k * 64 + lane);
         const size_t n_inner = ((size_t)1 << depth) - 1;
         const uint32_t n_blocks = 1u << (depth - 2);
         const uint32_t first_block_node = n_blocks - 1;
@@ -417,9 +428,9 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
             for (int k = 0; k < K; ++k) {
                 // two dependent steps (the kernel is VALU-bound: this is ~half the instructions of evaluating
                 // both second-level nodes)
-                const bool c0 = q_go_right<MS>(q_xread(tile, na[k].x, pos[k]), na[k].x);
+                const bool c0 = q_go_right<MS>(q_xread<LDSX>(gx, na[k].x, pos[k]), na[k].x);
                 const uint32_t n1 = c0 ? na[k].z : na[k].y;
-                const bool c1 = q_go_right<MS>(q_xread(tile, n1, pos[k]), n1);
+                const bool c1 = q_go_right<MS>(q_xread<LDSX>(gx, n1, pos[k]), n1);
                 const uint32_t lo = c0 ? nb[k].z : nb[k].x, hi = c0 ? nb[k].w : nb[k].y;
                 v[k] = __uint_as_float(c1 ? hi : lo);
                 if (WRITE_LEAF) {
@@ -463,7 +474,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                     uint2 pr[K];
     #pragma unroll
                     for (int k = 0; k < K; ++k) {
-                        xc[k] = q_xread(tile, node[k], pos[k]);
+                        xc[k] = q_xread<LDSX>(gx, node[k], pos[k]);
                         pr[k] = *reinterpret_cast<const uint2 *>(&slot[2 * i[k]]);  // children 2i, 2i+1
                     }
     #pragma unroll
@@ -475,7 +486,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                 }
     #pragma unroll
                 for (int k = 0; k < K; ++k) {
-                    const uint32_t xc = q_xread(tile, node[k], pos[k]);
+                    const uint32_t xc = q_xread<LDSX>(gx, node[k], pos[k]);
                     i[k] = q_descend(i[k], q_right_mask<MS>(xc, node[k]));
                 }
             }
@@ -487,7 +498,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                     const uint32_t *tree = qinner + (size_t)t * n_inner;
                     for (int l = top_levels; l < depth - 2; ++l) {
                         const uint32_t n = tree[idx];
-                        const uint32_t xc = q_xread(tile, n, pos[k]);
+                        const uint32_t xc = q_xread<LDSX>(gx, n, pos[k]);
                         idx = 2u * idx + 1u + (q_go_right<MS>(xc, n) ? 1u : 0u);
                     }
                 }
@@ -518,11 +529,15 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
 }
 
 // ------------------------------------------------------------------------------------------------
-static long long qring_lds_for(const tahoe_forest *f, int nwalk)
+static long long qring_lds_for(const tahoe_forest *f, int nwalk, bool lds_tile = true)
 {
-    return (long long)f->p.num_cols * kQRows * 2 + (long long)nwalk * kQSlotBytes + (long long)kQRing * kQRows * 4 +
-           (kQRing + 1) * 4LL;
+    return (lds_tile ? (long long)f->p.num_cols * kQRows * 2 : 0) + (long long)nwalk * kQSlotBytes +
+           (long long)kQRing * kQRows * 4 + (kQRing + 1) * 4LL;
 }
+
+constexpr int kGxWalkers = 15;  // walkers of the GX form (no LDS tile)
+// true: the 128-row u16 tile fits LDS beside at least 4 walkers; false: GX form
+bool qring_lds_tile(const tahoe_forest *f) { return qring_lds_for(f, 4) <= f->lds_limit; }
 
 int qring_walkers(const tahoe_forest *f)
 {
@@ -535,13 +550,13 @@ int qring_walkers(const tahoe_forest *f)
     }
     for (int n : options)
         if (qring_lds_for(f, n) <= f->lds_limit) return n;
-    return 0;
+    return kGxWalkers;  // rows too wide for an LDS tile: features are read from the quantised tile in L2
 }
 
 long long qring_lds_bytes(const tahoe_forest *f)
 {
     const int n = qring_walkers(f);
-    return n ? qring_lds_for(f, n) : 0;
+    return n ? qring_lds_for(f, n, qring_lds_tile(f)) : 0;
 }
 
 template <typename T>
@@ -558,10 +573,10 @@ static hipError_t q_upload(T **dst, const T *src, size_t count, size_t *total)
 template <int NWALK>
 static hipError_t q_allow(long long lds)
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&qring_kernel<NWALK, false>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&qring_kernel<NWALK, false, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&qring_kernel<NWALK, true>),
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&qring_kernel<NWALK, true, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
@@ -737,6 +752,15 @@ tahoe_status qring_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner,
     if (qring_lds_for(f, 12) <= f->lds_limit && (e = q_allow<12>(qring_lds_for(f, 12))) != hipSuccess) return bad("attr12");
     if (qring_lds_for(f, 8) <= f->lds_limit && (e = q_allow<8>(qring_lds_for(f, 8))) != hipSuccess) return bad("attr8");
     if (qring_lds_for(f, 4) <= f->lds_limit && (e = q_allow<4>(qring_lds_for(f, 4))) != hipSuccess) return bad("attr4");
+    {
+        const int lds = (int)qring_lds_for(f, kGxWalkers, false);
+        if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&qring_kernel<kGxWalkers, false, false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess)
+            return bad("attr(gx)");
+        if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&qring_kernel<kGxWalkers, true, false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess)
+            return bad("attr(gx)");
+    }
     int pair_max = 0, single_max = 1;
     for (const tahoe_qgroup &g : q->groups) {
         pair_max = std::max(pair_max, g.pair_lds_floats);
@@ -790,20 +814,20 @@ tahoe_status qring_reserve(tahoe_forest *f, size_t rows)
     return TAHOE_OK;
 }
 
-template <int NWALK>
+template <int NWALK, bool LDSX = true>
 static void q_launch(tahoe_forest *f, const tahoe_qgroup &g, float *sums, const float *sums_in, uint32_t *leaf_out,
                      size_t rows, hipStream_t stream)
 {
     tahoe_qstate *q = f->q;
     const unsigned grid = (unsigned)((rows + kQRows - 1) / kQRows);
-    const int lds = (int)qring_lds_for(f, NWALK);
+    const int lds = (int)qring_lds_for(f, NWALK, LDSX);
     const uint32_t *leaf_orig = f->leaf_orig + (size_t)g.tree_lo * f->n_leaf;
     if (leaf_out)
-        hipLaunchKernelGGL((qring_kernel<NWALK, true>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, g.top,
+        hipLaunchKernelGGL((qring_kernel<NWALK, true, LDSX>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, g.top,
                            g.blocks, g.qinner, leaf_orig, sums, leaf_out, rows, f->p.num_cols, g.num_trees, f->depth,
                            q->top_levels, q->top_stride, q->chunk_flags, f->error_flag, sums_in, g.tree_lo, f->p.num_trees);
     else
-        hipLaunchKernelGGL((qring_kernel<NWALK, false>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, g.top,
+        hipLaunchKernelGGL((qring_kernel<NWALK, false, LDSX>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, g.top,
                            g.blocks, g.qinner, leaf_orig, sums, leaf_out, rows, f->p.num_cols, g.num_trees, f->depth,
                            q->top_levels, q->top_stride, q->chunk_flags, f->error_flag, sums_in, g.tree_lo, f->p.num_trees);
 }
@@ -837,6 +861,9 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
         TAHOE_HIP_TRY(hipGetLastError());
         if (first && mid_event) TAHOE_HIP_TRY(hipEventRecord(mid_event, stream));  // splits pre-pass / walk for 1 group
         const float *sums_in = first ? nullptr : sums;  // later groups continue the running float32 sums
+        if (!qring_lds_tile(f))
+            q_launch<kGxWalkers, false>(f, g, sums, sums_in, leaf_out, rows, stream);
+        else
         switch (nwalk) {
             case 15: q_launch<15>(f, g, sums, sums_in, leaf_out, rows, stream); break;
             case 12: q_launch<12>(f, g, sums, sums_in, leaf_out, rows, stream); break;

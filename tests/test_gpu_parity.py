@@ -195,7 +195,8 @@ def test_invalid_forests_are_rejected(env):
     with pytest.raises(ta.TahoeError) as e:
         f.set_strategy(ta.STRATEGY_ROWTILE)
     assert e.value.status == 7
-    assert f.get_strategy(100) == ta.STRATEGY_DIRECT
+    # too wide for any LDS row tile: AUTO takes the quantised walk with feature codes read from L2 (GX form)
+    assert f.get_strategy(100) == ta.STRATEGY_QRING and f.info().qring_walkers == 15
 
 
 def test_golden_fixtures(env):
