@@ -17,7 +17,9 @@
  *                                                    -> tahoe_device_* / tahoe_compare_device
  * Every device pointer is a HIP device pointer on the handle's device; `stream` is a hipStream_t
  * passed as void* (NULL = the default stream).  All predict calls are asynchronous on `stream`
- * and allocate nothing.
+ * and allocate nothing, with one exception: the QRING strategy keeps a 2-byte-per-value quantised
+ * copy of the batch in a grow-only workspace; a batch larger than any before grows it (allocation +
+ * device synchronisation) unless tahoe_forest_reserve sized it beforehand.
  *
  * There is no CPU fallback: every compute entry point fails with TAHOE_ERR_NO_DEVICE when no
  * gfx950 device is usable.
