@@ -851,13 +851,6 @@ static hipError_t upload(T **dst, const std::vector<T> &src, size_t *total)
     return e;
 }
 
-template <typename K>
-static hipError_t allow_lds(K kernel, long long bytes)
-{
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)bytes);
-}
-
 }  // namespace tahoe
 
 using namespace tahoe;
@@ -1018,14 +1011,12 @@ tahoe_status tahoe_forest_create(tahoe_forest **out, const tahoe_dense_node *nod
 
     // Kernels that may need more than the default 64 KiB of dynamic LDS.
     if (rowtile_fits(f)) {
-        const int lds = rowtile_lds_bytes(p->num_cols, f->lds_levels);
-        if ((e = allow_lds(&rowtile_kernel<false>, lds)) != hipSuccess) return bail(e, "hipFuncSetAttribute(rowtile)");
-        if ((e = allow_lds(&rowtile_kernel<true>, lds)) != hipSuccess) return bail(e, "hipFuncSetAttribute(rowtile)");
+        if ((e = allow_max_lds(reinterpret_cast<const void *>(&rowtile_kernel<false>), f->lds_limit)) != hipSuccess) return bail(e, "hipFuncSetAttribute(rowtile)");
+        if ((e = allow_max_lds(reinterpret_cast<const void *>(&rowtile_kernel<true>), f->lds_limit)) != hipSuccess) return bail(e, "hipFuncSetAttribute(rowtile)");
     }
     if (f->has_blocks && tileblock_lds_bytes(f, 128) <= f->lds_limit) {
-        const long long lds = tileblock_lds_bytes(f, 128);
-        if ((e = allow_lds(&tileblock_kernel<128, false>, lds)) != hipSuccess) return bail(e, "hipFuncSetAttribute(tileblock)");
-        if ((e = allow_lds(&tileblock_kernel<128, true>, lds)) != hipSuccess) return bail(e, "hipFuncSetAttribute(tileblock)");
+        if ((e = allow_max_lds(reinterpret_cast<const void *>(&tileblock_kernel<128, false>), f->lds_limit)) != hipSuccess) return bail(e, "hipFuncSetAttribute(tileblock)");
+        if ((e = allow_max_lds(reinterpret_cast<const void *>(&tileblock_kernel<128, true>), f->lds_limit)) != hipSuccess) return bail(e, "hipFuncSetAttribute(tileblock)");
     }
     if ((e = hipMalloc(reinterpret_cast<void **>(&f->error_flag), sizeof(int))) != hipSuccess)
         return bail(e, "hipMalloc(error_flag)");
@@ -1038,19 +1029,16 @@ tahoe_status tahoe_forest_create(tahoe_forest **out, const tahoe_dense_node *nod
         }
     }
     if (f->has_blocks && tilering_lds_bytes(f, 64) <= f->lds_limit) {
-        const long long lds = tilering_lds_bytes(f, 64);
-        if ((e = allow_lds(&tilering_kernel<64, 8, false>, lds)) != hipSuccess) return bail(e, "hipFuncSetAttribute(tilering)");
-        if ((e = allow_lds(&tilering_kernel<64, 8, true>, lds)) != hipSuccess) return bail(e, "hipFuncSetAttribute(tilering)");
+        if ((e = allow_max_lds(reinterpret_cast<const void *>(&tilering_kernel<64, 8, false>), f->lds_limit)) != hipSuccess) return bail(e, "hipFuncSetAttribute(tilering)");
+        if ((e = allow_max_lds(reinterpret_cast<const void *>(&tilering_kernel<64, 8, true>), f->lds_limit)) != hipSuccess) return bail(e, "hipFuncSetAttribute(tilering)");
     }
     if (f->has_blocks && tilering_lds_bytes(f, 128) <= f->lds_limit) {
-        const long long lds = tilering_lds_bytes(f, 128);
-        if ((e = allow_lds(&tilering_kernel<128, 4, false>, lds)) != hipSuccess) return bail(e, "hipFuncSetAttribute(tilering)");
-        if ((e = allow_lds(&tilering_kernel<128, 4, true>, lds)) != hipSuccess) return bail(e, "hipFuncSetAttribute(tilering)");
+        if ((e = allow_max_lds(reinterpret_cast<const void *>(&tilering_kernel<128, 4, false>), f->lds_limit)) != hipSuccess) return bail(e, "hipFuncSetAttribute(tilering)");
+        if ((e = allow_max_lds(reinterpret_cast<const void *>(&tilering_kernel<128, 4, true>), f->lds_limit)) != hipSuccess) return bail(e, "hipFuncSetAttribute(tilering)");
     }
     if (f->has_blocks && tileblock_lds_bytes(f, 64) <= f->lds_limit) {
-        const long long lds = tileblock_lds_bytes(f, 64);
-        if ((e = allow_lds(&tileblock_kernel<64, false>, lds)) != hipSuccess) return bail(e, "hipFuncSetAttribute(tileblock)");
-        if ((e = allow_lds(&tileblock_kernel<64, true>, lds)) != hipSuccess) return bail(e, "hipFuncSetAttribute(tileblock)");
+        if ((e = allow_max_lds(reinterpret_cast<const void *>(&tileblock_kernel<64, false>), f->lds_limit)) != hipSuccess) return bail(e, "hipFuncSetAttribute(tileblock)");
+        if ((e = allow_max_lds(reinterpret_cast<const void *>(&tileblock_kernel<64, true>), f->lds_limit)) != hipSuccess) return bail(e, "hipFuncSetAttribute(tileblock)");
     }
     *out = f;
     return TAHOE_OK;

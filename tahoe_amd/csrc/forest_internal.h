@@ -73,6 +73,16 @@ struct tahoe_forest {
 
 namespace tahoe {
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is per function and process-wide, not per handle: always raise it to
+// the device limit (less the kernel's static LDS), so that handles of different shapes can coexist in one process.
+inline hipError_t allow_max_lds(const void *fn, int limit)
+{
+    hipFuncAttributes a;
+    hipError_t e = hipFuncGetAttributes(&a, fn);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, limit - (int)a.sharedSizeBytes);
+}
+
 // The branch rule of infer_one_tree, BaseTahoeTest.h:450-453: 1 = right child.
 __device__ __forceinline__ uint32_t go_right(float x, float thr, bool def_left, float missing)
 {

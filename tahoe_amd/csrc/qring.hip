@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(kQuantPairThreads)
     const bool together = size0 + size1 <= lds_floats;
     const size_t r0 = chunk * kQuantRowsPerBlock;
     const size_t r1 = min(rows, r0 + (size_t)kQuantRowsPerBlock);
-    constexpr int U = 2;
+    constexpr int U = 4;  // rows per thread and iteration: 8 independent search chains hide the LDS latency
     bool saw_missing = false;
     for (int pass = 0; pass < (together ? 1 : 2); ++pass) {
         if (pass) __syncthreads();  // everyone is done reading the first tree
@@ -573,11 +573,9 @@ static hipError_t q_upload(T **dst, const T *src, size_t count, size_t *total)
 template <int NWALK>
 static hipError_t q_allow(long long lds)
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&qring_kernel<NWALK, false, true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = allow_max_lds(reinterpret_cast<const void *>(&qring_kernel<NWALK, false, true>), (int)lds);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&qring_kernel<NWALK, true, true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    return allow_max_lds(reinterpret_cast<const void *>(&qring_kernel<NWALK, true, true>), (int)lds);
 }
 
 // Builds one tree group [lo, hi).  Returns TAHOE_OK with *too_many = the largest per-feature count when that
@@ -748,31 +746,17 @@ tahoe_status qring_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner,
     // kernels that need more than 64 KiB of dynamic LDS
     hipError_t e;
     auto bad = [&](const char *what) { return fail(TAHOE_ERR_HIP, "qring_build: %s failed: %s", what, hipGetErrorString(e)); };
-    if (qring_lds_for(f, 15) <= f->lds_limit && (e = q_allow<15>(qring_lds_for(f, 15))) != hipSuccess) return bad("attr15");
-    if (qring_lds_for(f, 12) <= f->lds_limit && (e = q_allow<12>(qring_lds_for(f, 12))) != hipSuccess) return bad("attr12");
-    if (qring_lds_for(f, 8) <= f->lds_limit && (e = q_allow<8>(qring_lds_for(f, 8))) != hipSuccess) return bad("attr8");
-    if (qring_lds_for(f, 4) <= f->lds_limit && (e = q_allow<4>(qring_lds_for(f, 4))) != hipSuccess) return bad("attr4");
-    {
-        const int lds = (int)qring_lds_for(f, kGxWalkers, false);
-        if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&qring_kernel<kGxWalkers, false, false>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess)
-            return bad("attr(gx)");
-        if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&qring_kernel<kGxWalkers, true, false>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess)
-            return bad("attr(gx)");
-    }
-    int pair_max = 0, single_max = 1;
-    for (const tahoe_qgroup &g : q->groups) {
-        pair_max = std::max(pair_max, g.pair_lds_floats);
-        single_max = std::max(single_max, g.max_table);
-    }
-    if (pair_max * 4 > 64 * 1024 &&
-        (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&quantize_pair_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, pair_max * 4)) != hipSuccess)
+    if (qring_lds_for(f, 15) <= f->lds_limit && (e = q_allow<15>(f->lds_limit)) != hipSuccess) return bad("attr15");
+    if (qring_lds_for(f, 12) <= f->lds_limit && (e = q_allow<12>(f->lds_limit)) != hipSuccess) return bad("attr12");
+    if (qring_lds_for(f, 8) <= f->lds_limit && (e = q_allow<8>(f->lds_limit)) != hipSuccess) return bad("attr8");
+    if (qring_lds_for(f, 4) <= f->lds_limit && (e = q_allow<4>(f->lds_limit)) != hipSuccess) return bad("attr4");
+    if ((e = allow_max_lds(reinterpret_cast<const void *>(&qring_kernel<kGxWalkers, false, false>), f->lds_limit)) != hipSuccess)
+        return bad("attr(gx)");
+    if ((e = allow_max_lds(reinterpret_cast<const void *>(&qring_kernel<kGxWalkers, true, false>), f->lds_limit)) != hipSuccess)
+        return bad("attr(gx)");
+    if ((e = allow_max_lds(reinterpret_cast<const void *>(&quantize_pair_kernel), f->lds_limit)) != hipSuccess)
         return bad("attr(quantize_pair)");
-    if (single_max * 4 > 64 * 1024 &&
-        (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&quantize_kernel<1>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, single_max * 4)) != hipSuccess)
+    if ((e = allow_max_lds(reinterpret_cast<const void *>(&quantize_kernel<1>), f->lds_limit)) != hipSuccess)
         return bad("attr(quantize)");
     return TAHOE_OK;
 }

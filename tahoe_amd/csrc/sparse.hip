@@ -221,12 +221,9 @@ tahoe_status tahoe_sparse_forest_create(tahoe_forest **out, const int32_t *trees
     if (p->num_trees && (e = hipMemcpy(sp->trees, trees, (size_t)p->num_trees * sizeof(int32_t), hipMemcpyHostToDevice)) != hipSuccess)
         return bail(e, "hipMemcpy(trees)");
     if (sparse_tile_fits(f)) {
-        const int lds = (int)sparse_lds(f, true);
-        if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sparse_kernel<true, false>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess)
+        if ((e = allow_max_lds(reinterpret_cast<const void *>(&sparse_kernel<true, false>), f->lds_limit)) != hipSuccess)
             return bail(e, "hipFuncSetAttribute(sparse)");
-        if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sparse_kernel<true, true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess)
+        if ((e = allow_max_lds(reinterpret_cast<const void *>(&sparse_kernel<true, true>), f->lds_limit)) != hipSuccess)
             return bail(e, "hipFuncSetAttribute(sparse)");
     }
     *out = f;

@@ -324,3 +324,29 @@ def test_qring_missing_only_in_a_late_chunk_and_workspace_growth(env):
         f.check()
         assert np.array_equal(bits(leaf.cpu().numpy()), want_leaf), n
         assert np.array_equal(bits(sums.cpu().numpy()), bits(want)), n
+
+
+def test_handles_of_different_shapes_coexist(env):
+    """The dynamic-LDS attribute is per kernel and process-wide: a small forest created after a large one must not
+    lower it under the large one's launch size.  Both handles stay usable in any order, on every strategy."""
+    ta, oracle, torch = env
+    big_n = ta.synth_forest(12, 12, 256, seed=61)
+    big_x = ta.synth_data(700, 256, seed=62, missing_prob=0.05, missing=MISSING)
+    small_n = ta.synth_forest(5, 4, 3, seed=63)
+    small_x = ta.synth_data(300, 3, seed=64, missing_prob=0.05, missing=MISSING)
+    big = ta.Forest(big_n, 12, 12, 256, missing=MISSING)
+    small = ta.Forest(small_n, 5, 4, 3, missing=MISSING)
+    want_big = oracle.predict(big_n, 12, 12, big_x, MISSING)[0]
+    want_small = oracle.predict(small_n, 5, 4, small_x, MISSING)[0]
+    bx, sx = torch.from_numpy(big_x).cuda(), torch.from_numpy(small_x).cuda()
+    for s in (ta.STRATEGY_AUTO, ta.STRATEGY_ROWTILE, ta.STRATEGY_TILEBLOCK, ta.STRATEGY_TILERING, ta.STRATEGY_QRING):
+        big.set_strategy(s)
+        small.set_strategy(s)
+        got_s = small.predict_raw(sx)
+        got_b = big.predict_raw(bx)
+        big.check()
+        small.check()
+        assert np.array_equal(bits(got_b.cpu().numpy()), bits(want_big)), s
+        assert np.array_equal(bits(got_s.cpu().numpy()), bits(want_small)), s
+    big.close()
+    small.close()
