@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--strategy", type=int, default=0, help="0 auto, 1 direct, 2 rowtile, 3 tileblock, 4 tilering")
     ap.add_argument("--cpu-rows", type=int, default=100_000, help="rows of the batch timed on the CPU oracle")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-host", action="store_true", help="skip the host-resident (PCIe-inclusive) leg")
     args = ap.parse_args()
 
     import torch
@@ -151,6 +152,30 @@ def main():
                                  / HBM_PEAK_GBPS, 5),
     }
 
+    # ---- host-resident batch (rank 0, N = 1 only): the PCIe-inclusive rate, reported beside `value`, never as it ----
+    host_leg = None
+    if rank == 0 and world == 1 and not args.no_host:
+        fence()
+        ref = preds.cpu().numpy()
+        host_leg = {"unit": "samples/s", "note": "tahoe_forest_predict_host: rows start in host memory, chunked upload "
+                    "overlapped with the traversal, predictions back in host memory; PCIe-inclusive, not `value`"}
+        pin = ta.PinnedArray(R, C)
+        pin.array[:] = data
+        out_h = np.empty(R, dtype=np.float32)
+        for name, src in (("pinned", pin.array), ("pageable", data)):
+            forest.predict_host(src, out_h)  # creates the buffers / warms up
+            reps = 3
+            th = time.perf_counter()
+            for _ in range(reps):
+                forest.predict_host(src, out_h)
+            th = (time.perf_counter() - th) / reps
+            host_leg[name] = {"value": round(R / th, 1), "ms_per_batch": round(th * 1e3, 3),
+                              "GBps_over_link": round(R * C * 4 / th / 1e9, 2),
+                              "bitwise_equal_to_resident": bool(np.array_equal(out_h.view(np.uint32), ref.view(np.uint32)))}
+            if not host_leg[name]["bitwise_equal_to_resident"]:
+                raise SystemExit("bench: host-pipeline predictions differ from the resident-batch predictions")
+        pin.close()
+
     # ---- CPU baseline + parity spot check (rank 0, N = 1 only) ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -194,6 +219,7 @@ def main():
                        "strategy": ta.STRATEGY_NAMES.get(forest.get_strategy(R))},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "host_pipeline": host_leg,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

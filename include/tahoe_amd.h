@@ -173,6 +173,19 @@ tahoe_status tahoe_forest_check(tahoe_forest *f, void *stream);
  * quantised copy of the batch).  Optional: predict grows the workspace on demand, which is the only
  * case in which a predict call allocates (and synchronises the device). */
 tahoe_status tahoe_forest_reserve(tahoe_forest *f, size_t rows);
+
+/* Host-resident batch (the reference uploads the data file once, BaseTahoeTest.h:378-389, and
+ * has no per-batch host path).  Rows are uploaded in chunks of `chunk_rows` rows (0 = about 32 MiB of rows)
+ * through two device buffers; the upload of chunk i+1 overlaps the traversal of chunk i and the download of
+ * chunk i-1's predictions.  A pinned source (hipHostMalloc / hipHostRegister) is copied from directly,
+ * pageable memory is staged through pinned buffers by a few host threads.  Synchronous: preds_host is
+ * complete on return.  Results are identical to tahoe_forest_predict on the whole batch (rows are
+ * independent).  The buffers and three streams are created on first use and kept by the handle. */
+tahoe_status tahoe_forest_predict_host(tahoe_forest *f, float *preds_host, const float *data_host, size_t rows,
+                                       size_t chunk_rows);
+/* Pinned host memory for the call above (hipHostMalloc / hipHostFree). */
+tahoe_status tahoe_host_alloc(void **ptr, size_t bytes);
+tahoe_status tahoe_host_free(void *ptr);
 /* Strategy the next predict will run (after AUTO resolution for `rows`). */
 int tahoe_forest_get_strategy(const tahoe_forest *f, size_t rows);
 

@@ -5,6 +5,7 @@ fallback: without the built library, importing `tahoe_amd.capi` raises."""
 
 from .capi import (  # noqa: F401
     Forest,
+    PinnedArray,
     ForestParams,
     TahoeError,
     lib,

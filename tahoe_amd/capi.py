@@ -122,6 +122,9 @@ _PROTOS = {
     "tahoe_forest_get_strategy": (_i, [_vp, _sz]),
     "tahoe_forest_check": (_i, [_vp, _vp]),
     "tahoe_forest_reserve": (_i, [_vp, _sz]),
+    "tahoe_forest_predict_host": (_i, [_vp, _vp, _vp, _sz, _sz]),
+    "tahoe_host_alloc": (_i, [C.POINTER(_vp), _sz]),
+    "tahoe_host_free": (_i, [_vp]),
     "tahoe_forest_get_info": (_i, [_vp, C.POINTER(ForestInfo)]),
     "tahoe_forest_set_profiling": (_i, [_vp, _i]),
     "tahoe_forest_kernel_times": (_i, [_vp, _vp, _i, C.POINTER(_i)]),
@@ -155,6 +158,22 @@ EXPORTED_SYMBOLS = tuple(_PROTOS)
 
 
 # ---- host-side helpers (formats, synthetic inputs) ----
+class PinnedArray:
+    """float32 [rows, cols] array in pinned host memory (tahoe_host_alloc); `.array` is the numpy view."""
+
+    def __init__(self, rows: int, cols: int):
+        self._p = _vp()
+        _check(lib.tahoe_host_alloc(C.byref(self._p), max(rows * cols * 4, 4)), "tahoe_host_alloc")
+        buf = (C.c_float * (rows * cols)).from_address(self._p.value)
+        self.array = np.frombuffer(buf, dtype=np.float32).reshape(rows, cols)
+
+    def close(self) -> None:
+        if self._p:
+            self.array = None
+            _check(lib.tahoe_host_free(self._p), "tahoe_host_free")
+            self._p = None
+
+
 def tree_num_nodes(depth: int) -> int:
     return lib.tahoe_tree_num_nodes(depth)
 
@@ -309,6 +328,16 @@ class Forest:
 
     def reserve(self, rows: int) -> None:
         _check(lib.tahoe_forest_reserve(self._h, rows), "tahoe_forest_reserve")
+
+    def predict_host(self, data: np.ndarray, preds: np.ndarray = None, chunk_rows: int = 0) -> np.ndarray:
+        """Host-resident batch: chunked upload overlapped with the traversal (tahoe_forest_predict_host)."""
+        if data.dtype != np.float32 or data.ndim != 2 or data.shape[1] != self.num_cols or not data.flags.c_contiguous:
+            raise ValueError(f"data must be C-contiguous float32 [rows, {self.num_cols}]")
+        if preds is None:
+            preds = np.empty(data.shape[0], dtype=np.float32)
+        _check(lib.tahoe_forest_predict_host(self._h, preds.ctypes.data, data.ctypes.data, data.shape[0], chunk_rows),
+               "tahoe_forest_predict_host")
+        return preds
 
     def check(self, stream=None) -> None:
         """Waits for the stream; raises if a kernel flagged an internal error."""

@@ -56,6 +56,20 @@ tahoe_status tahoe_device_alloc(void **ptr, size_t bytes, int set_zero)
     return TAHOE_OK;
 }
 
+tahoe_status tahoe_host_alloc(void **ptr, size_t bytes)
+{
+    if (!ptr) return fail(TAHOE_ERR_INVALID_ARG, "null argument");
+    *ptr = nullptr;
+    TAHOE_HIP_TRY(hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return TAHOE_OK;
+}
+
+tahoe_status tahoe_host_free(void *ptr)
+{
+    if (ptr) TAHOE_HIP_TRY(hipHostFree(ptr));
+    return TAHOE_OK;
+}
+
 tahoe_status tahoe_device_free(void *ptr)
 {
     if (ptr) TAHOE_HIP_TRY(hipFree(ptr));

@@ -1053,6 +1053,7 @@ void tahoe_forest_destroy(tahoe_forest *f)
     if (f->top) (void)hipFree(f->top);
     if (f->blocks) (void)hipFree(f->blocks);
     if (f->error_flag) (void)hipFree(f->error_flag);
+    pipeline_destroy(f);
     qring_destroy(f);
     sparse_destroy(f);
     for (hipEvent_t e : f->ev_start) (void)hipEventDestroy(e);

@@ -10,6 +10,7 @@
 
 struct tahoe_qstate;  // quantised views + workspace, owned by qring.hip
 struct tahoe_sstate;  // sparse (irregular) forest, owned by sparse.hip
+struct tahoe_pstate;  // host-batch upload pipeline, owned by pipeline.hip
 
 namespace tahoe {
 
@@ -64,6 +65,7 @@ struct tahoe_forest {
     int *error_flag = nullptr;     // set by TILERING if a bounded spin ever times out
     tahoe_qstate *q = nullptr;     // QRING: rank-quantised forest + row workspace (qring.hip)
     tahoe_sstate *sp = nullptr;    // non-null: this handle is a sparse forest (sparse.hip); the dense views are unused
+    tahoe_pstate *pipe = nullptr;  // tahoe_forest_predict_host: chunk buffers, streams, events (created on first use)
     size_t device_bytes = 0;
     // Profiling: one hipEvent pair per traversal launch, read back after the stream has drained.
     bool profiling = false;
@@ -109,5 +111,6 @@ bool sparse_tile_fits(const tahoe_forest *f);
 tahoe_status sparse_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, const float *data, size_t rows,
                            hipStream_t stream, bool tile);
 void sparse_destroy(tahoe_forest *f);
+void pipeline_destroy(tahoe_forest *f);
 
 }  // namespace tahoe

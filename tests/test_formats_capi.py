@@ -119,6 +119,48 @@ def test_loader_edge_cases_follow_the_reference(ta, tmp_path):
     assert x2.shape == (2, 1) and miss2 == 0.5
 
 
+def test_parallel_loader_equals_the_sequential_reader(ta, tmp_path, monkeypatch):
+    """Files big enough to be cut into several byte ranges (one per loader thread): the multi-threaded reader, the
+    single-threaded one (TAHOE_LOADER_THREADS=1) and the oracle's fgets loop give the same bytes -- on a complete
+    file, on one truncated in the middle of a node (the tail repeats the last line), with blank lines, without a
+    final newline, and with a line longer than one fgets unit (falls back to the sequential reader)."""
+    T, D, C, R = 300, 7, 40, 6000
+    nodes = ta.synth_forest(T, D, C, seed=19, leaf_prob=0.1)
+    data = ta.synth_data(R, C, seed=20, missing_prob=0.05, missing=-999.0)
+    m, d = tmp_path / "m.txt", tmp_path / "d.txt"
+    ta.write_model(str(m), nodes, T, D)
+    ta.write_data(str(d), data, -999.0)
+    mtext, dtext = m.read_text(), d.read_text()
+    assert len(mtext) > 1_000_000 and len(dtext) > 1_000_000
+    mlines, dlines = mtext.split("\n"), dtext.split("\n")
+    variants = {
+        "complete": (mtext, dtext),
+        "truncated": ("\n".join(mlines[: len(mlines) * 2 // 3 + 2]) + "\n", "\n".join(dlines[: len(dlines) // 2]) + "\n"),
+        "no_final_newline": (mtext.rstrip("\n"), "\n".join(dlines[: len(dlines) // 3])),
+        "blank_lines": ("\n".join(mlines[:5000]) + "\n\n\n" + "\n".join(mlines[5000:]),
+                        "\n".join(dlines[:7000]) + "\n\n" + "\n".join(dlines[7000:])),
+        "long_line": ("\n".join(mlines[:9000]) + "\n" + "1" * 3000 + "\n" + "\n".join(mlines[9000:]),
+                      "\n".join(dlines[:9000]) + "\n" + " " * 1023 + "0.5\n" + "\n".join(dlines[9000:])),
+    }
+    for name, (mt, dt) in variants.items():
+        mp, dp = tmp_path / f"{name}.m.txt", tmp_path / f"{name}.d.txt"
+        mp.write_text(mt)
+        dp.write_text(dt)
+        monkeypatch.setenv("TAHOE_LOADER_THREADS", "8")
+        n8, T8, D8, x8, miss8 = both_loaders_agree(ta, str(mp), str(dp))
+        monkeypatch.setenv("TAHOE_LOADER_THREADS", "3")
+        n3, _, _ = ta.load_model(str(mp))
+        x3, _ = ta.load_data(str(dp))
+        monkeypatch.setenv("TAHOE_LOADER_THREADS", "1")
+        n1, T1, D1 = ta.load_model(str(mp))
+        x1, miss1 = ta.load_data(str(dp))
+        assert (T8, D8) == (T1, D1) == (T, D), name
+        assert n8.tobytes() == n1.tobytes() == n3.tobytes(), name
+        assert x8.tobytes() == x1.tobytes() == x3.tobytes(), name
+        if name == "complete":
+            assert n8.tobytes() == nodes.tobytes() and x8.tobytes() == data.tobytes()
+
+
 def test_synthetic_generators_are_deterministic_and_shardable(ta):
     a = ta.synth_data(100, 7, seed=5, missing_prob=0.1, missing=-1.0, nan_prob=0.1)
     b = np.concatenate([ta.synth_data(40, 7, seed=5, missing_prob=0.1, missing=-1.0, nan_prob=0.1),

@@ -350,3 +350,38 @@ def test_handles_of_different_shapes_coexist(env):
         assert np.array_equal(bits(got_s.cpu().numpy()), bits(want_small)), s
     big.close()
     small.close()
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_host_batches_through_the_upload_pipeline(env, pinned):
+    """tahoe_forest_predict_host: chunked upload overlapped with the traversal gives the same bits as one resident
+    batch -- several chunks with a ragged last one, a single chunk, chunk > rows, pageable and pinned sources,
+    and an output transform (applied per chunk on the device)."""
+    ta, oracle, torch = env
+    T, D, C, R = 40, 9, 24, 70_001
+    nodes = ta.synth_forest(T, D, C, seed=71, leaf_prob=0.05)
+    data = ta.synth_data(R, C, seed=72, missing_prob=0.03, missing=MISSING, nan_prob=0.01)
+    want = oracle.predict(nodes, T, D, data, MISSING, threads=8)[0]
+    want_avg = oracle.predict(nodes, T, D, data, MISSING, output=ta.OUT_AVG, global_bias=0.25, threads=8)[0]
+    f = ta.Forest(nodes, T, D, C, missing=MISSING)
+    g = ta.Forest(nodes, T, D, C, missing=MISSING, output=ta.OUT_AVG, global_bias=0.25)
+    pin = None
+    if pinned:
+        pin = ta.PinnedArray(R, C)
+        pin.array[:] = data
+        src = pin.array
+    else:
+        src = data
+    for chunk in (0, 32768, 10_000, R, 3 * R):
+        got = f.predict_host(src, chunk_rows=chunk)
+        assert np.array_equal(bits(got), bits(want)), chunk
+    for n in (1, 129, 20_000):  # shrinking batches reuse the buffers
+        got = f.predict_host(np.ascontiguousarray(src[:n]), chunk_rows=4096)
+        assert np.array_equal(bits(got), bits(want[:n])), n
+    got = g.predict_host(src, chunk_rows=16384)
+    assert np.array_equal(bits(got), bits(want_avg))
+    assert f.predict_host(np.empty((0, C), dtype=np.float32)).shape == (0,)
+    f.close()
+    g.close()
+    if pin is not None:
+        pin.close()
