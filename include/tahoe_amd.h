@@ -228,6 +228,22 @@ tahoe_status tahoe_load_model(const char *path, int *num_trees, int *depth, taho
 tahoe_status tahoe_load_data(const char *path, int *num_rows, int *num_cols, float *missing, float **data_out);
 tahoe_status tahoe_write_model(const char *path, int num_trees, int depth, const tahoe_dense_node *nodes);
 tahoe_status tahoe_write_data(const char *path, int num_rows, int num_cols, float missing, const float *data);
+
+/* ---- binary files (no counterpart in the reference, whose text formats cost ~2.5 s for the K3
+ * model and ~25 s for the K3 data on one core).  64-byte header + the payload as it sits in memory
+ * (dense_node_t AoS / row-major float32) + a checksum; TAHOE_ERR_IO on a foreign, truncated or corrupt file. */
+tahoe_status tahoe_save_model_bin(const char *path, int num_trees, int depth, const tahoe_dense_node *nodes);
+tahoe_status tahoe_load_model_bin(const char *path, int *num_trees, int *depth, tahoe_dense_node **nodes_out);
+tahoe_status tahoe_save_data_bin(const char *path, int num_rows, int num_cols, float missing, const float *data);
+tahoe_status tahoe_load_data_bin(const char *path, int *num_rows, int *num_cols, float *missing, float **data_out);
+/* Text file with a cache beside it ("<path>.tbin"): used when it records the text file's current size and
+ * mtime, else the text is parsed as by tahoe_load_model / tahoe_load_data and the cache rewritten (best
+ * effort).  *from_cache (may be NULL) tells which happened.  The BaseTahoeTest mirror uses these when the
+ * environment variable TAHOE_BIN_CACHE is set. */
+tahoe_status tahoe_load_model_cached(const char *path, int *num_trees, int *depth, tahoe_dense_node **nodes_out,
+                                     int *from_cache);
+tahoe_status tahoe_load_data_cached(const char *path, int *num_rows, int *num_cols, float *missing, float **data_out,
+                                    int *from_cache);
 void tahoe_free_host(void *p);
 
 /* ---- deterministic synthetic inputs: SplitMix64, counter-based ---- */

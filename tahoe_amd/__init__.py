@@ -10,7 +10,11 @@ from .capi import (  # noqa: F401
     TahoeError,
     lib,
     load_data,
+    load_data_bin,
     load_model,
+    load_model_bin,
+    save_data_bin,
+    save_model_bin,
     synth_data,
     synth_forest,
     write_data,

@@ -133,6 +133,12 @@ _PROTOS = {
     "tahoe_load_data": (_i, [C.c_char_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_f), C.POINTER(_vp)]),
     "tahoe_write_model": (_i, [C.c_char_p, _i, _i, _vp]),
     "tahoe_write_data": (_i, [C.c_char_p, _i, _i, _f, _vp]),
+    "tahoe_save_model_bin": (_i, [C.c_char_p, _i, _i, _vp]),
+    "tahoe_load_model_bin": (_i, [C.c_char_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_vp)]),
+    "tahoe_save_data_bin": (_i, [C.c_char_p, _i, _i, _f, _vp]),
+    "tahoe_load_data_bin": (_i, [C.c_char_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_f), C.POINTER(_vp)]),
+    "tahoe_load_model_cached": (_i, [C.c_char_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_vp), C.POINTER(_i)]),
+    "tahoe_load_data_cached": (_i, [C.c_char_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_f), C.POINTER(_vp), C.POINTER(_i)]),
     "tahoe_free_host": (None, [_vp]),
     "tahoe_synth_forest": (None, [_vp, _i, _i, _i, C.c_uint64, _f]),
     "tahoe_synth_data": (None, [_vp, _sz, _sz, _i, C.c_uint64, _f, _f, _f]),
@@ -178,31 +184,70 @@ def tree_num_nodes(depth: int) -> int:
     return lib.tahoe_tree_num_nodes(depth)
 
 
-def load_model(path: str, num_trees: int = 10, depth: int = 20):
-    """-> (nodes[NODE_DTYPE], num_trees, depth).  Defaults are the BaseTahoeTest ctor defaults."""
-    nt, d, ptr = _i(num_trees), _i(depth), _vp()
-    _check(lib.tahoe_load_model(os.fsencode(path), C.byref(nt), C.byref(d), C.byref(ptr)), "tahoe_load_model")
-    n = nt.value * tree_num_nodes(d.value)
+def _take_nodes(ptr, n):
     try:
         buf = (C.c_char * (n * NODE_DTYPE.itemsize)).from_address(ptr.value) if n else b""
-        nodes = np.frombuffer(buf, dtype=NODE_DTYPE, count=n).copy()
+        return np.frombuffer(buf, dtype=NODE_DTYPE, count=n).copy()
     finally:
         lib.tahoe_free_host(ptr)
-    return nodes, nt.value, d.value
 
 
-def load_data(path: str, num_rows: int = 1000, num_cols: int = 500, missing: float = 0.0):
-    """-> (data[rows, cols] float32, missing)."""
-    nr, nc, ms, ptr = _i(num_rows), _i(num_cols), _f(missing), _vp()
-    _check(lib.tahoe_load_data(os.fsencode(path), C.byref(nr), C.byref(nc), C.byref(ms), C.byref(ptr)),
-           "tahoe_load_data")
-    n = nr.value * nc.value
+def _take_floats(ptr, rows, cols):
+    n = rows * cols
     try:
         buf = (C.c_char * (n * 4)).from_address(ptr.value) if n else b""
-        data = np.frombuffer(buf, dtype=np.float32, count=n).copy().reshape(nr.value, nc.value)
+        return np.frombuffer(buf, dtype=np.float32, count=n).copy().reshape(rows, cols)
     finally:
         lib.tahoe_free_host(ptr)
-    return data, ms.value
+
+
+def load_model(path: str, num_trees: int = 10, depth: int = 20, cached: bool = False):
+    """-> (nodes[NODE_DTYPE], num_trees, depth).  Defaults are the BaseTahoeTest ctor defaults.
+    cached=True: use / refresh the binary cache "<path>.tbin" (tahoe_load_model_cached)."""
+    nt, d, ptr = _i(num_trees), _i(depth), _vp()
+    if cached:
+        _check(lib.tahoe_load_model_cached(os.fsencode(path), C.byref(nt), C.byref(d), C.byref(ptr), None),
+               "tahoe_load_model_cached")
+    else:
+        _check(lib.tahoe_load_model(os.fsencode(path), C.byref(nt), C.byref(d), C.byref(ptr)), "tahoe_load_model")
+    return _take_nodes(ptr, nt.value * tree_num_nodes(d.value)), nt.value, d.value
+
+
+def load_data(path: str, num_rows: int = 1000, num_cols: int = 500, missing: float = 0.0, cached: bool = False):
+    """-> (data[rows, cols] float32, missing)."""
+    nr, nc, ms, ptr = _i(num_rows), _i(num_cols), _f(missing), _vp()
+    if cached:
+        _check(lib.tahoe_load_data_cached(os.fsencode(path), C.byref(nr), C.byref(nc), C.byref(ms), C.byref(ptr), None),
+               "tahoe_load_data_cached")
+    else:
+        _check(lib.tahoe_load_data(os.fsencode(path), C.byref(nr), C.byref(nc), C.byref(ms), C.byref(ptr)),
+               "tahoe_load_data")
+    return _take_floats(ptr, nr.value, nc.value), ms.value
+
+
+def save_model_bin(path: str, nodes: np.ndarray, num_trees: int, depth: int) -> None:
+    nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
+    assert nodes.size == num_trees * tree_num_nodes(depth)
+    _check(lib.tahoe_save_model_bin(os.fsencode(path), num_trees, depth, nodes.ctypes.data), "tahoe_save_model_bin")
+
+
+def load_model_bin(path: str):
+    nt, d, ptr = _i(0), _i(0), _vp()
+    _check(lib.tahoe_load_model_bin(os.fsencode(path), C.byref(nt), C.byref(d), C.byref(ptr)), "tahoe_load_model_bin")
+    return _take_nodes(ptr, nt.value * tree_num_nodes(d.value)), nt.value, d.value
+
+
+def save_data_bin(path: str, data: np.ndarray, missing: float) -> None:
+    data = np.ascontiguousarray(data, dtype=np.float32)
+    _check(lib.tahoe_save_data_bin(os.fsencode(path), data.shape[0], data.shape[1], missing, data.ctypes.data),
+           "tahoe_save_data_bin")
+
+
+def load_data_bin(path: str):
+    nr, nc, ms, ptr = _i(0), _i(0), _f(0.0), _vp()
+    _check(lib.tahoe_load_data_bin(os.fsencode(path), C.byref(nr), C.byref(nc), C.byref(ms), C.byref(ptr)),
+           "tahoe_load_data_bin")
+    return _take_floats(ptr, nr.value, nc.value), ms.value
 
 
 def write_model(path: str, nodes: np.ndarray, num_trees: int, depth: int) -> None:

@@ -392,6 +392,243 @@ tahoe_status tahoe_write_data(const char *path, int num_rows, int num_cols, floa
     return TAHOE_OK;
 }
 
+// ---- binary cache: the text formats cost seconds to minutes at K3 size -------------------------
+// One 64-byte header, then the payload exactly as it sits in memory (dense_node_t AoS / row-major float32), so a
+// load is one read() into the array the caller gets.
+namespace {
+struct BinHeader {
+    char magic[8];  // "TAHOEBIN"
+    uint32_t version;
+    uint32_t kind;  // 1 model, 2 data
+    int32_t a, b;   // model: num_trees, depth; data: num_rows, num_cols
+    float missing;  // data only
+    uint32_t reserved;
+    uint64_t payload_bytes;
+    uint64_t checksum;    // of the payload
+    int64_t src_size;     // size and mtime of the text file this was parsed from (0 = not a cache of a text file)
+    int64_t src_mtime_ns;
+};
+static_assert(sizeof(BinHeader) == 64, "BinHeader is the on-disk layout");
+constexpr uint32_t kBinVersion = 1;
+
+// four independent multiply-add lanes over 64-bit words, folded; the tail bytes are zero-extended
+uint64_t payload_checksum(const void *p, size_t n)
+{
+    const uint64_t K = 0x9E3779B97F4A7C15ull;
+    uint64_t h[4] = {1, 2, 3, 4};
+    const unsigned char *b = static_cast<const unsigned char *>(p);
+    size_t i = 0;
+    for (; i + 32 <= n; i += 32) {
+        uint64_t w[4];
+        memcpy(w, b + i, 32);
+        for (int l = 0; l < 4; ++l) h[l] = (h[l] ^ w[l]) * K + 0x632BE59BD9B4E019ull;
+    }
+    uint64_t tail[4] = {0, 0, 0, 0};
+    memcpy(tail, b + i, n - i);
+    for (int l = 0; l < 4; ++l) h[l] = (h[l] ^ tail[l]) * K;
+    uint64_t r = n;
+    for (int l = 0; l < 4; ++l) r = (r ^ (h[l] >> 29) ^ h[l]) * K;
+    return r ^ (r >> 32);
+}
+
+tahoe_status write_bin(const char *path, uint32_t kind, int a, int b, float missing, const void *payload, size_t bytes,
+                       int64_t src_size, int64_t src_mtime_ns)
+{
+    BinHeader h;
+    memset(&h, 0, sizeof(h));
+    memcpy(h.magic, "TAHOEBIN", 8);
+    h.version = kBinVersion;
+    h.kind = kind;
+    h.a = a;
+    h.b = b;
+    h.missing = missing;
+    h.payload_bytes = bytes;
+    h.checksum = payload_checksum(payload, bytes);
+    h.src_size = src_size;
+    h.src_mtime_ns = src_mtime_ns;
+    // write beside the target, then rename: a reader never sees a half-written cache
+    const std::string tmp = std::string(path) + ".tmp" + std::to_string((long)getpid());
+    FILE *fp = fopen(tmp.c_str(), "wb");
+    if (!fp) return fail(TAHOE_ERR_IO, "cannot write %s: %s", tmp.c_str(), strerror(errno));
+    bool ok = fwrite(&h, sizeof(h), 1, fp) == 1 && (bytes == 0 || fwrite(payload, 1, bytes, fp) == bytes);
+    ok = (fclose(fp) == 0) && ok;
+    if (!ok || rename(tmp.c_str(), path) != 0) {
+        (void)remove(tmp.c_str());
+        return fail(TAHOE_ERR_IO, "write error on %s", path);
+    }
+    return TAHOE_OK;
+}
+
+// Reads and validates; *payload is malloc'ed.  want_src_*: when non-zero the header must name that text file state.
+tahoe_status read_bin(const char *path, uint32_t kind, BinHeader *h, void **payload, size_t elem_bytes)
+{
+    FILE *fp = fopen(path, "rb");
+    if (!fp) return fail(TAHOE_ERR_IO, "fail to read: %s: %s", path, strerror(errno));
+    if (fread(h, sizeof(*h), 1, fp) != 1 || memcmp(h->magic, "TAHOEBIN", 8) != 0) {
+        fclose(fp);
+        return fail(TAHOE_ERR_IO, "%s: not a tahoe binary file", path);
+    }
+    if (h->version != kBinVersion || h->kind != kind) {
+        fclose(fp);
+        return fail(TAHOE_ERR_IO, "%s: version %u kind %u, expected version %u kind %u", path, h->version, h->kind,
+                    kBinVersion, kind);
+    }
+    size_t count = 0;
+    bool shape_ok = false;
+    if (kind == 1 && h->a >= 0 && h->b >= 0 && h->b <= 30) {
+        count = (size_t)h->a * (size_t)tahoe_tree_num_nodes(h->b);
+        shape_ok = true;
+    } else if (kind == 2 && h->a >= 0 && h->b >= 0) {
+        count = (size_t)h->a * (size_t)h->b;
+        shape_ok = true;
+    }
+    if (!shape_ok || h->payload_bytes != count * elem_bytes) {
+        fclose(fp);
+        return fail(TAHOE_ERR_IO, "%s: header shape (%d, %d) does not match a payload of %llu bytes", path, h->a, h->b,
+                    (unsigned long long)h->payload_bytes);
+    }
+    void *buf = malloc(h->payload_bytes ? h->payload_bytes : 1);
+    if (!buf) {
+        fclose(fp);
+        return fail(TAHOE_ERR_NO_MEMORY, "%s: %llu bytes", path, (unsigned long long)h->payload_bytes);
+    }
+    const size_t got = h->payload_bytes ? fread(buf, 1, h->payload_bytes, fp) : 0;
+    const bool trailing = fgetc(fp) != EOF;
+    fclose(fp);
+    if (got != h->payload_bytes || trailing) {
+        free(buf);
+        return fail(TAHOE_ERR_IO, "%s: payload is %s than the header says", path, trailing ? "longer" : "shorter");
+    }
+    if (payload_checksum(buf, h->payload_bytes) != h->checksum) {
+        free(buf);
+        return fail(TAHOE_ERR_IO, "%s: payload checksum mismatch (corrupt file)", path);
+    }
+    *payload = buf;
+    return TAHOE_OK;
+}
+
+bool stat_source(const char *path, int64_t *size, int64_t *mtime_ns)
+{
+    struct stat st;
+    if (stat(path, &st) != 0) return false;
+    *size = (int64_t)st.st_size;
+    *mtime_ns = (int64_t)st.st_mtim.tv_sec * 1000000000ll + (int64_t)st.st_mtim.tv_nsec;
+    return true;
+}
+}  // namespace
+
+tahoe_status tahoe_save_model_bin(const char *path, int num_trees, int depth, const tahoe_dense_node *nodes)
+{
+    if (!path || num_trees < 0 || depth < 0 || depth > 30 || (!nodes && num_trees))
+        return fail(TAHOE_ERR_INVALID_ARG, "tahoe_save_model_bin: bad argument");
+    const size_t total = (size_t)num_trees * (size_t)tahoe_tree_num_nodes(depth);
+    return write_bin(path, 1, num_trees, depth, 0.f, nodes, total * sizeof(tahoe_dense_node), 0, 0);
+}
+
+tahoe_status tahoe_load_model_bin(const char *path, int *num_trees, int *depth, tahoe_dense_node **nodes_out)
+{
+    if (!path || !num_trees || !depth || !nodes_out)
+        return fail(TAHOE_ERR_INVALID_ARG, "tahoe_load_model_bin: null argument");
+    BinHeader h;
+    void *buf = nullptr;
+    tahoe_status st = read_bin(path, 1, &h, &buf, sizeof(tahoe_dense_node));
+    if (st != TAHOE_OK) return st;
+    *num_trees = h.a;
+    *depth = h.b;
+    *nodes_out = static_cast<tahoe_dense_node *>(buf);
+    return TAHOE_OK;
+}
+
+tahoe_status tahoe_save_data_bin(const char *path, int num_rows, int num_cols, float missing, const float *data)
+{
+    if (!path || num_rows < 0 || num_cols < 0 || (!data && (size_t)num_rows * (size_t)num_cols))
+        return fail(TAHOE_ERR_INVALID_ARG, "tahoe_save_data_bin: bad argument");
+    return write_bin(path, 2, num_rows, num_cols, missing, data, (size_t)num_rows * (size_t)num_cols * sizeof(float), 0, 0);
+}
+
+tahoe_status tahoe_load_data_bin(const char *path, int *num_rows, int *num_cols, float *missing, float **data_out)
+{
+    if (!path || !num_rows || !num_cols || !missing || !data_out)
+        return fail(TAHOE_ERR_INVALID_ARG, "tahoe_load_data_bin: null argument");
+    BinHeader h;
+    void *buf = nullptr;
+    tahoe_status st = read_bin(path, 2, &h, &buf, sizeof(float));
+    if (st != TAHOE_OK) return st;
+    *num_rows = h.a;
+    *num_cols = h.b;
+    *missing = h.missing;
+    *data_out = static_cast<float *>(buf);
+    return TAHOE_OK;
+}
+
+// Text file with a binary cache beside it ("<path>.tbin"): the cache is used when it names the text file's current
+// size and mtime, otherwise the text is parsed (exactly as tahoe_load_model / tahoe_load_data) and the cache is
+// rewritten, best effort.  The in/out defaults only matter on the text path; a cache stores what that path produced.
+tahoe_status tahoe_load_model_cached(const char *path, int *num_trees, int *depth, tahoe_dense_node **nodes_out, int *from_cache)
+{
+    if (!path || !num_trees || !depth || !nodes_out)
+        return fail(TAHOE_ERR_INVALID_ARG, "tahoe_load_model_cached: null argument");
+    if (from_cache) *from_cache = 0;
+    const std::string bin = std::string(path) + ".tbin";
+    int64_t size = 0, mtime = 0;
+    const bool have_src = stat_source(path, &size, &mtime);
+    if (have_src) {
+        BinHeader h;
+        void *buf = nullptr;
+        if (read_bin(bin.c_str(), 1, &h, &buf, sizeof(tahoe_dense_node)) == TAHOE_OK) {
+            if (h.src_size == size && h.src_mtime_ns == mtime) {
+                *num_trees = h.a;
+                *depth = h.b;
+                *nodes_out = static_cast<tahoe_dense_node *>(buf);
+                if (from_cache) *from_cache = 1;
+                clear_error();
+                return TAHOE_OK;
+            }
+            free(buf);
+        }
+        clear_error();
+    }
+    tahoe_status st = tahoe_load_model(path, num_trees, depth, nodes_out);
+    if (st != TAHOE_OK) return st;
+    const size_t total = (size_t)*num_trees * (size_t)tahoe_tree_num_nodes(*depth);
+    if (write_bin(bin.c_str(), 1, *num_trees, *depth, 0.f, *nodes_out, total * sizeof(tahoe_dense_node), size, mtime) != TAHOE_OK)
+        clear_error();  // a read-only directory is not an error for the load
+    return TAHOE_OK;
+}
+
+tahoe_status tahoe_load_data_cached(const char *path, int *num_rows, int *num_cols, float *missing, float **data_out, int *from_cache)
+{
+    if (!path || !num_rows || !num_cols || !missing || !data_out)
+        return fail(TAHOE_ERR_INVALID_ARG, "tahoe_load_data_cached: null argument");
+    if (from_cache) *from_cache = 0;
+    const std::string bin = std::string(path) + ".tbin";
+    int64_t size = 0, mtime = 0;
+    const bool have_src = stat_source(path, &size, &mtime);
+    if (have_src) {
+        BinHeader h;
+        void *buf = nullptr;
+        if (read_bin(bin.c_str(), 2, &h, &buf, sizeof(float)) == TAHOE_OK) {
+            if (h.src_size == size && h.src_mtime_ns == mtime) {
+                *num_rows = h.a;
+                *num_cols = h.b;
+                *missing = h.missing;
+                *data_out = static_cast<float *>(buf);
+                if (from_cache) *from_cache = 1;
+                clear_error();
+                return TAHOE_OK;
+            }
+            free(buf);
+        }
+        clear_error();
+    }
+    tahoe_status st = tahoe_load_data(path, num_rows, num_cols, missing, data_out);
+    if (st != TAHOE_OK) return st;
+    if (write_bin(bin.c_str(), 2, *num_rows, *num_cols, *missing, *data_out,
+                  (size_t)*num_rows * (size_t)*num_cols * sizeof(float), size, mtime) != TAHOE_OK)
+        clear_error();
+    return TAHOE_OK;
+}
+
 void tahoe_free_host(void *p) { free(p); }
 
 void tahoe_synth_forest(tahoe_dense_node *nodes, int num_trees, int depth, int num_cols, uint64_t seed,

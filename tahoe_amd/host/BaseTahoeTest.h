@@ -138,7 +138,11 @@ class BaseTahoeTest {
     void generate_forest_from_file()
     {
         tahoe_dense_node *loaded = nullptr;
-        if (tahoe_load_model(ps.input_model_file, &ps.num_trees, &ps.depth, &loaded) != TAHOE_OK) {
+        // TAHOE_BIN_CACHE set: keep "<file>.tbin" beside the text file and read that while it is current
+        const tahoe_status st = getenv("TAHOE_BIN_CACHE")
+                                    ? tahoe_load_model_cached(ps.input_model_file, &ps.num_trees, &ps.depth, &loaded, nullptr)
+                                    : tahoe_load_model(ps.input_model_file, &ps.num_trees, &ps.depth, &loaded);
+        if (st != TAHOE_OK) {
             fprintf(stderr, "%s\n", tahoe_last_error());  // the reference: perror("fail to read"); exit(1)
             exit(1);
         }
@@ -149,7 +153,11 @@ class BaseTahoeTest {
     void generate_data_from_file()
     {
         float *loaded = nullptr;
-        if (tahoe_load_data(ps.input_data_file, &ps.num_rows, &ps.num_cols, &ps.missing, &loaded) != TAHOE_OK) {
+        const tahoe_status st =
+            getenv("TAHOE_BIN_CACHE")
+                ? tahoe_load_data_cached(ps.input_data_file, &ps.num_rows, &ps.num_cols, &ps.missing, &loaded, nullptr)
+                : tahoe_load_data(ps.input_data_file, &ps.num_rows, &ps.num_cols, &ps.missing, &loaded);
+        if (st != TAHOE_OK) {
             fprintf(stderr, "%s\n", tahoe_last_error());
             exit(1);
         }

@@ -161,6 +161,55 @@ def test_parallel_loader_equals_the_sequential_reader(ta, tmp_path, monkeypatch)
             assert n8.tobytes() == nodes.tobytes() and x8.tobytes() == data.tobytes()
 
 
+def test_binary_files_and_text_cache(ta, tmp_path):
+    T, D, C, R = 9, 5, 13, 57
+    nodes = ta.synth_forest(T, D, C, seed=29, leaf_prob=0.2)
+    data = ta.synth_data(R, C, seed=30, missing_prob=0.1, missing=-999.0, nan_prob=0.1)
+    mb, db = str(tmp_path / "m.tbin"), str(tmp_path / "d.tbin")
+    ta.save_model_bin(mb, nodes, T, D)
+    ta.save_data_bin(db, data, -999.0)
+    n2, T2, D2 = ta.load_model_bin(mb)
+    x2, miss = ta.load_data_bin(db)
+    assert (T2, D2, miss) == (T, D, -999.0) and n2.tobytes() == nodes.tobytes() and x2.tobytes() == data.tobytes()
+    # wrong kind, foreign file, truncation, one flipped payload bit -> TAHOE_ERR_IO
+    bad = tmp_path / "bad.tbin"
+    raw = open(db, "rb").read()
+    cases = {"kind": None, "foreign": b"12\n3\n", "short": raw[:-5], "long": raw + b"x",
+             "bitflip": raw[:200] + bytes([raw[200] ^ 4]) + raw[201:]}
+    for name, content in cases.items():
+        with pytest.raises(ta.TahoeError) as e:
+            if content is None:
+                ta.load_model_bin(db)
+            else:
+                bad.write_bytes(content)
+                ta.load_data_bin(str(bad))
+        assert e.value.status == 2, name
+    # empty payloads
+    ta.save_data_bin(db, np.empty((0, 4), dtype=np.float32), 1.5)
+    x0, m0 = ta.load_data_bin(db)
+    assert x0.shape == (0, 4) and m0 == 1.5
+    # text + cache: first load parses and writes "<path>.tbin", second reads it, a changed text file invalidates it
+    m, d = str(tmp_path / "m.txt"), str(tmp_path / "d.txt")
+    ta.write_model(m, nodes, T, D)
+    ta.write_data(d, data, -999.0)
+    for _ in range(2):
+        n3, T3, D3 = ta.load_model(m, cached=True)
+        x3, miss3 = ta.load_data(d, cached=True)
+        assert (T3, D3, miss3) == (T, D, -999.0) and n3.tobytes() == nodes.tobytes() and x3.tobytes() == data.tobytes()
+        assert os.path.exists(m + ".tbin") and os.path.exists(d + ".tbin")
+    flag = ctypes.c_int(-1)
+    nt, dd, ptr = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_void_p()
+    assert ta.lib.tahoe_load_model_cached(m.encode(), ctypes.byref(nt), ctypes.byref(dd), ctypes.byref(ptr), ctypes.byref(flag)) == 0
+    ta.lib.tahoe_free_host(ptr)
+    assert flag.value == 1
+    data2 = data.copy()
+    data2[3, 2] = 42.0
+    ta.write_data(d, data2, -999.0)
+    os.utime(d, ns=(1, 1))  # same size is possible; the mtime differs
+    x4, _ = ta.load_data(d, cached=True)
+    assert x4.tobytes() == data2.tobytes()
+
+
 def test_synthetic_generators_are_deterministic_and_shardable(ta):
     a = ta.synth_data(100, 7, seed=5, missing_prob=0.1, missing=-1.0, nan_prob=0.1)
     b = np.concatenate([ta.synth_data(40, 7, seed=5, missing_prob=0.1, missing=-1.0, nan_prob=0.1),
