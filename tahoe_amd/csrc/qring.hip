@@ -46,6 +46,13 @@ struct tahoe_qgroup {
     int pair_lds_floats = 0;      // LDS floats of quantize_pair_kernel; 0 = odd num_cols, single-feature form
     float *tables = nullptr;      // concatenated search trees
     int *offsets = nullptr;       // [cols + 1]
+    // bucketed form (quantize_bucket_pair_kernel): sorted thresholds + a direct-index table per feature
+    int buckets = 0;              // B (power of two); 0 = form unavailable for this group
+    int bucket_lds_bytes = 0;     // LDS of the largest feature pair
+    float *bsorted = nullptr;     // per feature: n_f sorted thresholds + (2^steps_f - 1) NaN pads
+    int *boffsets = nullptr;      // [cols + 1] into bsorted
+    uint16_t *bstarts = nullptr;  // [cols][B + 2]: first sorted index of each bucket (entry B = n_f)
+    float4 *bparams = nullptr;    // [cols]: lo, scale, steps (int bits), unused
     uint32_t *top = nullptr;      // [T_g][top_stride]
     uint4 *blocks = nullptr;      // [T_g][2^(De-2)][2]
     uint32_t *qinner = nullptr;   // [T_g][2^De - 1] (only when have_mid)
@@ -55,6 +62,7 @@ struct tahoe_qstate {
     int top_levels = 0;
     bool have_mid = false;        // De - 2 > top_levels: heap of quantised nodes for the middle levels
     int top_stride = 0;           // u32 entries per tree in `top` (>= 4)
+    bool narrow = false;          // node words in the NARROW layout (num_cols <= 256, 15 walkers, LDS tile)
     std::vector<tahoe_qgroup> groups;
     uint16_t *xq = nullptr;       // workspace: quantised tiles (re-used by every group)
     size_t xq_rows = 0;           // rows the workspace holds
@@ -245,6 +253,122 @@ __global__ void __launch_bounds__(kQuantPairThreads)
     if (__ballot(saw_missing) != 0 && (threadIdx.x & 63) == 0) atomicOr(&chunk_flags[chunk], 1u);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Bucketed form of the same conversion.  code(x) = #{e <= x} needs ~log2(n) dependent LDS probes in a search
+// tree (14 at K3, the kernel's whole cost: bank conflicts on 64 random probes).  A monotone map
+// bucket(x) = clamp(trunc((x - lo) * scale), 0, B - 1) splits the sorted thresholds into B runs; monotone means
+// every threshold in a lower bucket is < x and every one in a higher bucket is > x, so
+//   code(x) = start[bucket(x)] + #{e in x's bucket : e <= x}
+// exactly, whatever the distribution -- a skewed one only makes some runs longer.  The run is searched with a
+// fixed number of branch-free steps (steps_f = ceil(log2(longest run + 1)), over a window that may reach into the
+// following runs (> x, harmless) and, at the end of the array, into NaN padding.  The thresholds' own buckets are
+// computed by bucket_index_kernel with the very same q_bucket() on the device, so host and device arithmetic
+// never have to agree.  NaN x: fmaxf(NaN, 0) = 0 -> bucket 0, every compare false -> code 0, as before.
+__device__ __forceinline__ int q_bucket(float x, float lo, float scale, float bm1)
+{
+    float t = (x - lo) * scale;
+    t = fminf(fmaxf(t, 0.0f), bm1);  // NaN -> 0; +-inf clamp
+    return (int)t;
+}
+
+__global__ void bucket_index_kernel(const float *__restrict__ vals, const int *__restrict__ feat, const float4 *__restrict__ params,
+                                    float bm1, int n, int *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = params[feat[i]];
+    out[i] = q_bucket(vals[i], p.x, p.y, bm1);
+}
+
+__global__ void __launch_bounds__(kQuantPairThreads)
+    quantize_bucket_pair_kernel(const float *__restrict__ data, const float *__restrict__ bsorted, const int *__restrict__ boffsets,
+                                const uint16_t *__restrict__ bstarts, const float4 *__restrict__ bparams,
+                                uint16_t *__restrict__ xq, uint32_t *__restrict__ chunk_flags, size_t rows, int cols, float missing,
+                                int B)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned nblk = gridDim.x;
+    const unsigned vid = (nblk % 8u == 0u) ? (blockIdx.x % 8u) * (nblk / 8u) + blockIdx.x / 8u : blockIdx.x;  // XCD-contiguous
+    const int groups = cols / 2;
+    const int f0 = (int)(vid % groups) * 2;
+    const size_t chunk = vid / groups;
+    const int base0 = boffsets[f0], base1 = boffsets[f0 + 1];
+    const int len0 = base1 - base0, len1 = boffsets[f0 + 2] - base1;
+    float *s0 = reinterpret_cast<float *>(smem);
+    float *s1 = s0 + len0;
+    uint16_t *st0 = reinterpret_cast<uint16_t *>(s1 + len1);
+    uint16_t *st1 = st0 + (B + 2);
+    for (int i = threadIdx.x; i < len0; i += blockDim.x) s0[i] = bsorted[base0 + i];
+    for (int i = threadIdx.x; i < len1; i += blockDim.x) s1[i] = bsorted[base1 + i];
+    {   // both start tables are adjacent in global memory too: (B + 2) u16 each, copied as dwords
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(bstarts + (size_t)f0 * (B + 2));
+        uint32_t *dst = reinterpret_cast<uint32_t *>(st0);
+        for (int i = threadIdx.x; i < B + 2; i += blockDim.x) dst[i] = src[i];
+    }
+    const float4 p0 = bparams[f0], p1 = bparams[f0 + 1];
+    const int steps0 = __float_as_int(p0.z), steps1 = __float_as_int(p1.z);
+    const float bm1 = (float)(B - 1);
+    __syncthreads();
+    const size_t r0 = chunk * kQuantRowsPerBlock;
+    const size_t r1 = min(rows, r0 + (size_t)kQuantRowsPerBlock);
+    constexpr int U = 4;
+    bool saw_missing = false;
+    for (size_t rb = r0 + threadIdx.x; rb < r1; rb += (size_t)blockDim.x * U) {
+        float2 xv[U];
+        int c0[U], c1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t r = min(rb + (size_t)u * blockDim.x, r1 - 1);  // clamped: in bounds, result unused
+            xv[u] = *reinterpret_cast<const float2 *>(data + r * (size_t)cols + f0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {  // positions are kept in bytes: one add forms the probe address
+            c0[u] = 4 * (int)st0[q_bucket(xv[u].x, p0.x, p0.y, bm1)];
+            c1[u] = 4 * (int)st1[q_bucket(xv[u].y, p1.x, p1.y, bm1)];
+        }
+        // branch-free upper bound inside the window [c, c + 2^steps - 1): c += half when s[c + half - 1] <= x
+        const char *b0 = reinterpret_cast<const char *>(s0) - 4, *b1 = reinterpret_cast<const char *>(s1) - 4;
+        int k = max(steps0, steps1) - 1;
+        for (; k >= min(steps0, steps1); --k) {  // the longer window's extra steps
+            const int half4 = 4 << k;
+            if (steps0 > steps1) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) c0[u] += (*reinterpret_cast<const float *>(b0 + c0[u] + half4) <= xv[u].x) ? half4 : 0;
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u) c1[u] += (*reinterpret_cast<const float *>(b1 + c1[u] + half4) <= xv[u].y) ? half4 : 0;
+            }
+        }
+        for (; k >= 0; --k) {  // both features: 2 * U independent probes in flight
+            const int half4 = 4 << k;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float v0 = *reinterpret_cast<const float *>(b0 + c0[u] + half4);
+                const float v1 = *reinterpret_cast<const float *>(b1 + c1[u] + half4);
+                c0[u] += (v0 <= xv[u].x) ? half4 : 0;
+                c1[u] += (v1 <= xv[u].y) ? half4 : 0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            c0[u] >>= 2;
+            c1[u] >>= 2;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t r = rb + (size_t)u * blockDim.x;
+            if (r < r1) {
+                uint16_t *dst = xq + (r / kQRows) * ((size_t)cols * kQRows) + (size_t)f0 * kQRows + qrow_pos((int)(r % kQRows));
+                const bool ms0 = fabsf(xv[u].x - missing) <= kMissingEps, ms1 = fabsf(xv[u].y - missing) <= kMissingEps;
+                saw_missing |= ms0 | ms1;
+                dst[0] = (uint16_t)(ms0 ? kCodeMissing : (uint32_t)c0[u]);
+                dst[kQRows] = (uint16_t)(ms1 ? kCodeMissing : (uint32_t)c1[u]);
+            }
+        }
+    }
+    if (__ballot(saw_missing) != 0 && (threadIdx.x & 63) == 0) atomicOr(&chunk_flags[chunk], 1u);
+}
+
 // Ring flags: relaxed workgroup-scope accesses (plain ds_read/ds_write that the compiler neither caches
 // in a register nor reorders across the asm memory barriers around them).
 __device__ __forceinline__ uint32_t lds_flag_load(const uint32_t *p)
@@ -261,19 +385,22 @@ __device__ __forceinline__ void lds_flag_store(uint32_t *p, uint32_t v)
 // predicate of v_cndmask / v_addc (hipcc's ?: form materialises both booleans in VGPRs: 6 more VALU).
 // MS = false is the fast path for row chunks in which the quantise pass met no missing value (it
 // reports that per chunk): the rule is then the single compare.
-template <bool MS>
+// NARROW (num_cols <= 256): node = code << 16 | fid << 8 | def_left, so that the feature column's LDS offset
+// (fid * 256) is a bit field of the node word and one v_bfi forms the read address (q_xread).
+template <bool MS, bool NARROW>
 __device__ __forceinline__ uint64_t q_right_mask(uint32_t xc, uint32_t node)
 {
-    const uint64_t ge = __builtin_amdgcn_uicmp(xc, node & 0xFFFFu, 35 /* ICMP_UGE */);
+    const uint64_t ge = __builtin_amdgcn_uicmp(xc, NARROW ? node >> 16 : node & 0xFFFFu, 35 /* ICMP_UGE */);
     if (!MS) return ge;
     const uint64_t ms = __builtin_amdgcn_uicmp(xc, kCodeMissing, 32 /* ICMP_EQ */);
-    const uint64_t ndl = __builtin_amdgcn_sicmp((int)node, -1, 38 /* ICMP_SGT: bit 31 (def_left) clear */);
+    const uint64_t ndl = NARROW ? __builtin_amdgcn_uicmp(node & 0xFFu, 0u, 32 /* ICMP_EQ: def_left clear */)
+                                : __builtin_amdgcn_sicmp((int)node, -1, 38 /* ICMP_SGT: bit 31 (def_left) clear */);
     return (ge & ~ms) | (ms & ndl);
 }
-template <bool MS>
+template <bool MS, bool NARROW>
 __device__ __forceinline__ bool q_go_right(uint32_t xc, uint32_t node)
 {
-    return __builtin_amdgcn_inverse_ballot_w64(q_right_mask<MS>(xc, node));
+    return __builtin_amdgcn_inverse_ballot_w64(q_right_mask<MS, NARROW>(xc, node));
 }
 // i <- 2i + (lane's bit of mask): one v_addc with the mask as carry-in
 __device__ __forceinline__ uint32_t q_descend(uint32_t i, uint64_t right_mask)
@@ -291,21 +418,28 @@ __device__ __forceinline__ uint32_t q_descend(uint32_t i, uint64_t right_mask)
 // the quantised tile in global memory (L2-resident: one 128-row tile of 3072 columns is 768 KiB); `gx` = the
 // tile's base, posb = byte position inside a column.
 typedef const uint16_t __attribute__((address_space(3))) *lds_u16_ptr;
-template <bool LDSX>
+template <bool LDSX, bool NARROW>
 __device__ __forceinline__ uint32_t q_xread(const unsigned char *gx, uint32_t node, uint32_t posb)
 {
+    if (LDSX && NARROW) {
+        // the tile starts at LDS address 0 (checked at kernel entry) and posb < 256: address = node[15:8] : posb[7:0]
+        uint32_t addr;
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(addr) : "s"(0xFF00u), "v"(node), "v"(posb));
+        return *reinterpret_cast<lds_u16_ptr>(addr);
+    }
     if (LDSX) {
         uint32_t addr;  // asm: hipcc re-canonicalises the C form into shift + and + add
         asm("v_bfe_u32 %0, %1, 16, 15\n\tv_lshl_add_u32 %0, %0, 8, %2" : "=&v"(addr) : "v"(node), "v"(posb));
         return *reinterpret_cast<lds_u16_ptr>(addr);
     }
+    if (NARROW) return *reinterpret_cast<const uint16_t *>(gx + (node & 0xFF00u) + posb);
     return *reinterpret_cast<const uint16_t *>(gx + (((node >> 16) & 0x7fffu) << 8) + posb);
 }
 
 // ------------------------------------------------------------------------------------------------
 // (2) the walk.  Dynamic LDS: tile [cols][128] u16 | NWALK slots of (4 << L) bytes | ring [16][128] f32 |
 // ready[16] | consumed.
-template <int NWALK, bool WRITE_LEAF, bool LDSX>
+template <int NWALK, bool WRITE_LEAF, bool LDSX, bool NARROW = false>
 __global__ void __launch_bounds__((NWALK + 1) * 64)
     qring_kernel(const uint16_t *__restrict__ xq, const uint32_t *__restrict__ top, const uint4 *__restrict__ blocks,
                  const uint32_t *__restrict__ qinner, const uint32_t *__restrict__ leaf_orig, float *__restrict__ sums,
@@ -329,6 +463,11 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
     uint32_t *consumed = ring_ready + kQRing;
 
     const size_t row0 = (size_t)blockIdx.x * kQRows;
+    if (LDSX && NARROW && (uint32_t)reinterpret_cast<uintptr_t>(tile) != 0u) {
+        // q_xread's v_bfi needs the tile at LDS address 0 (true while the kernel has no static LDS)
+        if (tid == 0) atomicOr(error_flag, 2);
+        return;
+    }
 
     // ---- stage the quantised tile (already in LDS order): straight 16-byte copies ----
     if (LDSX) {
@@ -428,9 +567,9 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
             for (int k = 0; k < K; ++k) {
                 // two dependent steps (the kernel is VALU-bound: this is ~half the instructions of evaluating
                 // both second-level nodes)
-                const bool c0 = q_go_right<MS>(q_xread<LDSX>(gx, na[k].x, pos[k]), na[k].x);
+                const bool c0 = q_go_right<MS, NARROW>(q_xread<LDSX, NARROW>(gx, na[k].x, pos[k]), na[k].x);
                 const uint32_t n1 = c0 ? na[k].z : na[k].y;
-                const bool c1 = q_go_right<MS>(q_xread<LDSX>(gx, n1, pos[k]), n1);
+                const bool c1 = q_go_right<MS, NARROW>(q_xread<LDSX, NARROW>(gx, n1, pos[k]), n1);
                 const uint32_t lo = c0 ? nb[k].z : nb[k].x, hi = c0 ? nb[k].w : nb[k].y;
                 v[k] = __uint_as_float(c1 ? hi : lo);
                 if (WRITE_LEAF) {
@@ -474,20 +613,20 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                     uint2 pr[K];
     #pragma unroll
                     for (int k = 0; k < K; ++k) {
-                        xc[k] = q_xread<LDSX>(gx, node[k], pos[k]);
+                        xc[k] = q_xread<LDSX, NARROW>(gx, node[k], pos[k]);
                         pr[k] = *reinterpret_cast<const uint2 *>(&slot[2 * i[k]]);  // children 2i, 2i+1
                     }
     #pragma unroll
                     for (int k = 0; k < K; ++k) {
-                        const uint64_t cm = q_right_mask<MS>(xc[k], node[k]);
+                        const uint64_t cm = q_right_mask<MS, NARROW>(xc[k], node[k]);
                         i[k] = q_descend(i[k], cm);
                         node[k] = __builtin_amdgcn_inverse_ballot_w64(cm) ? pr[k].y : pr[k].x;
                     }
                 }
     #pragma unroll
                 for (int k = 0; k < K; ++k) {
-                    const uint32_t xc = q_xread<LDSX>(gx, node[k], pos[k]);
-                    i[k] = q_descend(i[k], q_right_mask<MS>(xc, node[k]));
+                    const uint32_t xc = q_xread<LDSX, NARROW>(gx, node[k], pos[k]);
+                    i[k] = q_descend(i[k], q_right_mask<MS, NARROW>(xc, node[k]));
                 }
             }
             uint32_t bsel[K];
@@ -498,8 +637,8 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                     const uint32_t *tree = qinner + (size_t)t * n_inner;
                     for (int l = top_levels; l < depth - 2; ++l) {
                         const uint32_t n = tree[idx];
-                        const uint32_t xc = q_xread<LDSX>(gx, n, pos[k]);
-                        idx = 2u * idx + 1u + (q_go_right<MS>(xc, n) ? 1u : 0u);
+                        const uint32_t xc = q_xread<LDSX, NARROW>(gx, n, pos[k]);
+                        idx = 2u * idx + 1u + (q_go_right<MS, NARROW>(xc, n) ? 1u : 0u);
                     }
                 }
                 bsel[k] = idx - first_block_node;
@@ -542,6 +681,7 @@ bool qring_lds_tile(const tahoe_forest *f) { return qring_lds_for(f, 4) <= f->ld
 int qring_walkers(const tahoe_forest *f)
 {
     if (!f->q) return 0;
+    if (f->q->narrow) return 15;  // the node words were encoded for that form at create
     static const int options[] = {15, 12, 8, 4};
     if (const char *e = getenv("TAHOE_QRING_WALKERS")) {  // tuning knob for experiments
         const int want = atoi(e);
@@ -575,7 +715,128 @@ static hipError_t q_allow(long long lds)
 {
     hipError_t e = allow_max_lds(reinterpret_cast<const void *>(&qring_kernel<NWALK, false, true>), (int)lds);
     if (e != hipSuccess) return e;
-    return allow_max_lds(reinterpret_cast<const void *>(&qring_kernel<NWALK, true, true>), (int)lds);
+    e = allow_max_lds(reinterpret_cast<const void *>(&qring_kernel<NWALK, true, true>), (int)lds);
+    if (e != hipSuccess || NWALK != 15) return e;
+    e = allow_max_lds(reinterpret_cast<const void *>(&qring_kernel<15, false, true, true>), (int)lds);
+    if (e != hipSuccess) return e;
+    return allow_max_lds(reinterpret_cast<const void *>(&qring_kernel<15, true, true, true>), (int)lds);
+}
+
+// Bucketed quantiser tables for one group (see quantize_bucket_pair_kernel).  Leaves g.buckets = 0 when the form is
+// unavailable (odd num_cols, a feature pair that does not fit LDS at any bucket count, TAHOE_QUANT_BUCKETS=0).
+static tahoe_status build_buckets(tahoe_forest *f, const std::vector<std::vector<float>> &tab, tahoe_qgroup &g)
+{
+    const int cols = f->p.num_cols;
+    g.buckets = 0;
+    if (cols % 2 != 0) return TAHOE_OK;
+    if (const char *e = getenv("TAHOE_QUANT_BUCKETS"))
+        if (atoi(e) == 0) return TAHOE_OK;
+    size_t total = 0;
+    for (int c = 0; c < cols; ++c) total += tab[c].size();
+    std::vector<float> vals;
+    std::vector<int> feat;
+    vals.reserve(total);
+    feat.reserve(total);
+    for (int c = 0; c < cols; ++c)
+        for (float v : tab[c]) {
+            vals.push_back(v);
+            feat.push_back(c);
+        }
+    hipError_t e = hipSuccess;
+    float *d_vals = nullptr;
+    int *d_feat = nullptr, *d_out = nullptr;
+    float4 *d_params = nullptr;
+    auto cleanup = [&]() {
+        for (void *p : {(void *)d_vals, (void *)d_feat, (void *)d_out, (void *)d_params})
+            if (p) (void)hipFree(p);
+    };
+    auto bad = [&](const char *what) {
+        cleanup();
+        return fail(TAHOE_ERR_HIP, "qring_build(buckets): %s failed: %s", what, hipGetErrorString(e));
+    };
+    const size_t n1 = std::max<size_t>(total, 1);
+    if ((e = hipMalloc(reinterpret_cast<void **>(&d_vals), n1 * sizeof(float))) != hipSuccess) return bad("hipMalloc");
+    if ((e = hipMalloc(reinterpret_cast<void **>(&d_feat), n1 * sizeof(int))) != hipSuccess) return bad("hipMalloc");
+    if ((e = hipMalloc(reinterpret_cast<void **>(&d_out), n1 * sizeof(int))) != hipSuccess) return bad("hipMalloc");
+    if ((e = hipMalloc(reinterpret_cast<void **>(&d_params), (size_t)cols * sizeof(float4))) != hipSuccess) return bad("hipMalloc");
+    if (total) {
+        if ((e = hipMemcpy(d_vals, vals.data(), total * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) return bad("hipMemcpy");
+        if ((e = hipMemcpy(d_feat, feat.data(), total * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess) return bad("hipMemcpy");
+    }
+    std::vector<int> bucket(total);
+    for (int B = 4096; B >= 256; B >>= 1) {
+        std::vector<float4> params((size_t)cols);
+        for (int c = 0; c < cols; ++c) {
+            float lo = 0.f, hi = 0.f;
+            bool any = false;
+            for (float v : tab[c])
+                if (std::isfinite(v)) {
+                    lo = any ? std::min(lo, v) : v;
+                    hi = any ? std::max(hi, v) : v;
+                    any = true;
+                }
+            float scale = (any && hi > lo) ? (float)B / (hi - lo) : 0.f;
+            if (!std::isfinite(scale)) scale = 0.f;
+            params[c] = make_float4(lo, scale, 0.f, 0.f);
+        }
+        if ((e = hipMemcpy(d_params, params.data(), (size_t)cols * sizeof(float4), hipMemcpyHostToDevice)) != hipSuccess)
+            return bad("hipMemcpy");
+        if (total) {
+            hipLaunchKernelGGL(bucket_index_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, d_vals, d_feat, d_params,
+                               (float)(B - 1), (int)total, d_out);
+            if ((e = hipGetLastError()) != hipSuccess) return bad("bucket_index_kernel");
+            if ((e = hipMemcpy(bucket.data(), d_out, total * sizeof(int), hipMemcpyDeviceToHost)) != hipSuccess) return bad("hipMemcpy");
+        }
+        // runs, window sizes, LDS need
+        std::vector<int> boffsets((size_t)cols + 1, 0);
+        std::vector<uint16_t> starts((size_t)cols * (B + 2), 0);
+        std::vector<int> steps((size_t)cols, 0);
+        bool monotone = true;
+        size_t at = 0;
+        int len_total = 0;
+        for (int c = 0; c < cols; ++c) {
+            const int n = (int)tab[c].size();
+            uint16_t *st = &starts[(size_t)c * (B + 2)];
+            int longest = 0, i = 0;
+            for (int b = 0; b <= B; ++b) {
+                // st[b] = first index whose bucket is >= b
+                while (i < n && bucket[at + i] < b) ++i;
+                st[b] = (uint16_t)i;
+                if (b > 0) longest = std::max(longest, (int)st[b] - (int)st[b - 1]);
+            }
+            st[B + 1] = (uint16_t)n;
+            for (int k = 0; k < n; ++k) {
+                if (bucket[at + k] < 0 || bucket[at + k] >= B || (k > 0 && bucket[at + k] < bucket[at + k - 1])) monotone = false;
+            }
+            int sp = 0;
+            while ((1 << sp) - 1 < longest) ++sp;
+            steps[c] = sp;
+            boffsets[c] = len_total;
+            len_total += n + (1 << sp) - 1;
+            memcpy(&params[c].z, &sp, 4);
+            at += (size_t)n;
+        }
+        boffsets[cols] = len_total;
+        if (!monotone) break;  // cannot happen with a monotone q_bucket; be safe and keep the search-tree form
+        int lds = 0;
+        for (int c = 0; c < cols; c += 2) lds = std::max(lds, (boffsets[c + 2] - boffsets[c]) * 4 + 2 * (B + 2) * 2);
+        if (lds > f->lds_limit - 256) continue;  // try fewer buckets (smaller start tables)
+        std::vector<float> bsorted((size_t)len_total, std::nanf(""));
+        at = 0;
+        for (int c = 0; c < cols; ++c) {
+            std::copy(tab[c].begin(), tab[c].end(), bsorted.begin() + boffsets[c]);
+            at += tab[c].size();
+        }
+        if ((e = q_upload(&g.bsorted, bsorted.data(), bsorted.size(), &f->device_bytes)) != hipSuccess) return bad("bsorted");
+        if ((e = q_upload(&g.boffsets, boffsets.data(), boffsets.size(), &f->device_bytes)) != hipSuccess) return bad("boffsets");
+        if ((e = q_upload(&g.bstarts, starts.data(), starts.size(), &f->device_bytes)) != hipSuccess) return bad("bstarts");
+        if ((e = q_upload(&g.bparams, params.data(), params.size(), &f->device_bytes)) != hipSuccess) return bad("bparams");
+        g.buckets = B;
+        g.bucket_lds_bytes = lds;
+        break;
+    }
+    cleanup();
+    return TAHOE_OK;
 }
 
 // Builds one tree group [lo, hi).  Returns TAHOE_OK with *too_many = the largest per-feature count when that
@@ -644,7 +905,7 @@ static tahoe_status build_group(tahoe_forest *f, const std::vector<InnerNode> &h
             const auto &v = tab[fid];
             code = (uint32_t)(std::lower_bound(v.begin(), v.end(), n.thr) - v.begin()) + 1u;
         }
-        return code | (fid << 16) | (dl << 31);
+        return q->narrow ? (code << 16) | (fid << 8) | dl : code | (fid << 16) | (dl << 31);
     };
     const size_t Tg = hi - lo;
     g.tree_lo = (int)lo;
@@ -690,6 +951,10 @@ static tahoe_status build_group(tahoe_forest *f, const std::vector<InnerNode> &h
         }
         g.pair_lds_floats = std::max(need, 1);
     }
+    {
+        const tahoe_status bs = build_buckets(f, tab, g);
+        if (bs != TAHOE_OK) return bs;
+    }
     hipError_t e;
     auto bad = [&](const char *what) { return fail(TAHOE_ERR_HIP, "qring_build: %s failed: %s", what, hipGetErrorString(e)); };
     if ((e = q_upload(&g.tables, tables.data(), tables.size(), &f->device_bytes)) != hipSuccess) return bad("tables");
@@ -703,7 +968,8 @@ static tahoe_status build_group(tahoe_forest *f, const std::vector<InnerNode> &h
 
 static void free_group(tahoe_qgroup &g)
 {
-    for (void *p : {(void *)g.tables, (void *)g.offsets, (void *)g.top, (void *)g.blocks, (void *)g.qinner})
+    for (void *p : {(void *)g.tables, (void *)g.offsets, (void *)g.top, (void *)g.blocks, (void *)g.qinner, (void *)g.bsorted,
+                    (void *)g.boffsets, (void *)g.bstarts, (void *)g.bparams})
         if (p) (void)hipFree(p);
     g = tahoe_qgroup();
 }
@@ -720,6 +986,10 @@ tahoe_status qring_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner,
     q->top_levels = f->top_levels;
     q->have_mid = f->depth - 2 > q->top_levels;
     q->top_stride = (int)std::max<size_t>((size_t)1 << q->top_levels, 4);  // >= 16 bytes per tree
+    {
+        const char *e = getenv("TAHOE_QRING_NARROW");  // experiments: 0 keeps the general node layout
+        q->narrow = cols <= 256 && qring_walkers(f) == 15 && qring_lds_tile(f) && !(e && atoi(e) == 0);
+    }
     // ---- cut the forest into tree groups whose features each see <= kQMaxTable distinct thresholds ----
     size_t lo = 0, gsize = T;
     while (lo < T) {
@@ -756,6 +1026,8 @@ tahoe_status qring_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner,
         return bad("attr(gx)");
     if ((e = allow_max_lds(reinterpret_cast<const void *>(&quantize_pair_kernel), f->lds_limit)) != hipSuccess)
         return bad("attr(quantize_pair)");
+    if ((e = allow_max_lds(reinterpret_cast<const void *>(&quantize_bucket_pair_kernel), f->lds_limit)) != hipSuccess)
+        return bad("attr(quantize_bucket_pair)");
     if ((e = allow_max_lds(reinterpret_cast<const void *>(&quantize_kernel<1>), f->lds_limit)) != hipSuccess)
         return bad("attr(quantize)");
     return TAHOE_OK;
@@ -798,7 +1070,7 @@ tahoe_status qring_reserve(tahoe_forest *f, size_t rows)
     return TAHOE_OK;
 }
 
-template <int NWALK, bool LDSX = true>
+template <int NWALK, bool LDSX = true, bool NARROW = false>
 static void q_launch(tahoe_forest *f, const tahoe_qgroup &g, float *sums, const float *sums_in, uint32_t *leaf_out,
                      size_t rows, hipStream_t stream)
 {
@@ -807,11 +1079,11 @@ static void q_launch(tahoe_forest *f, const tahoe_qgroup &g, float *sums, const 
     const int lds = (int)qring_lds_for(f, NWALK, LDSX);
     const uint32_t *leaf_orig = f->leaf_orig + (size_t)g.tree_lo * f->n_leaf;
     if (leaf_out)
-        hipLaunchKernelGGL((qring_kernel<NWALK, true, LDSX>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, g.top,
+        hipLaunchKernelGGL((qring_kernel<NWALK, true, LDSX, NARROW>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, g.top,
                            g.blocks, g.qinner, leaf_orig, sums, leaf_out, rows, f->p.num_cols, g.num_trees, f->depth,
                            q->top_levels, q->top_stride, q->chunk_flags, f->error_flag, sums_in, g.tree_lo, f->p.num_trees);
     else
-        hipLaunchKernelGGL((qring_kernel<NWALK, false, LDSX>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, g.top,
+        hipLaunchKernelGGL((qring_kernel<NWALK, false, LDSX, NARROW>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, g.top,
                            g.blocks, g.qinner, leaf_orig, sums, leaf_out, rows, f->p.num_cols, g.num_trees, f->depth,
                            q->top_levels, q->top_stride, q->chunk_flags, f->error_flag, sums_in, g.tree_lo, f->p.num_trees);
 }
@@ -834,7 +1106,11 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
         const bool pair_ok = g.pair_lds_floats > 0 && (reinterpret_cast<uintptr_t>(data) % 8) == 0;  // float2 loads
         const size_t qgrid = chunks * (size_t)(pair_ok ? f->p.num_cols / 2 : f->p.num_cols);
         if (qgrid > 0x7fffffffu) return fail(TAHOE_ERR_INVALID_ARG, "too many rows x cols for one launch");
-        if (pair_ok)
+        if (pair_ok && g.buckets > 0)
+            hipLaunchKernelGGL(quantize_bucket_pair_kernel, dim3((unsigned)qgrid), dim3(kQuantPairThreads),
+                               (size_t)g.bucket_lds_bytes, stream, data, g.bsorted, g.boffsets, g.bstarts, g.bparams, q->xq,
+                               q->chunk_flags, rows, f->p.num_cols, f->p.missing, g.buckets);
+        else if (pair_ok)
             hipLaunchKernelGGL(quantize_pair_kernel, dim3((unsigned)qgrid), dim3(kQuantPairThreads),
                                (size_t)g.pair_lds_floats * 4, stream, data, g.tables, g.offsets, q->xq, q->chunk_flags, rows,
                                f->p.num_cols, f->p.missing, g.pair_lds_floats);
@@ -849,7 +1125,12 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
             q_launch<kGxWalkers, false>(f, g, sums, sums_in, leaf_out, rows, stream);
         else
         switch (nwalk) {
-            case 15: q_launch<15>(f, g, sums, sums_in, leaf_out, rows, stream); break;
+            case 15:
+                if (q->narrow)
+                    q_launch<15, true, true>(f, g, sums, sums_in, leaf_out, rows, stream);
+                else
+                    q_launch<15>(f, g, sums, sums_in, leaf_out, rows, stream);
+                break;
             case 12: q_launch<12>(f, g, sums, sums_in, leaf_out, rows, stream); break;
             case 8: q_launch<8>(f, g, sums, sums_in, leaf_out, rows, stream); break;
             default: q_launch<4>(f, g, sums, sums_in, leaf_out, rows, stream); break;

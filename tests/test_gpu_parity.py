@@ -385,3 +385,38 @@ def test_host_batches_through_the_upload_pipeline(env, pinned):
     g.close()
     if pin is not None:
         pin.close()
+
+
+@pytest.mark.parametrize("buckets", ["1", "0"])
+def test_quantiser_on_skewed_thresholds(env, monkeypatch, buckets):
+    """The bucketed quantiser maps x to a run of the sorted thresholds with a monotone linear map; a skewed
+    distribution (almost everything in a sliver of the range, a few huge outliers, one constant feature, one
+    feature with only infinite thresholds) makes some runs long but may not change a single code.  Feature values
+    sit on thresholds, one ulp either side of them, and far outside.  Both quantiser forms (TAHOE_QUANT_BUCKETS)
+    against the oracle."""
+    ta, oracle, torch = env
+    monkeypatch.setenv("TAHOE_QUANT_BUCKETS", buckets)
+    rng = np.random.default_rng(11)
+    T, D, C, R = 60, 9, 8, 6000
+    nodes = ta.synth_forest(T, D, C, seed=81)
+    bits_u = nodes["bits"].view(np.uint32)
+    inner = (bits_u >> 31) == 0
+    fid = bits_u & ((1 << 30) - 1)
+    n_inner = int(inner.sum())
+    thr = np.empty(n_inner, dtype=np.float32)
+    f_in = fid[inner]
+    u = rng.random(n_inner)
+    thr[:] = (1.0 + 1e-4 * rng.standard_normal(n_inner)).astype(np.float32)          # a sliver around 1
+    thr[u < 0.02] = (rng.standard_normal(int((u < 0.02).sum())) * 1e30).astype(np.float32)  # outliers
+    thr[f_in == 1] = np.float32(0.75)                                                 # constant feature
+    thr[f_in == 2] = np.where(rng.random(int((f_in == 2).sum())) < 0.5, np.inf, -np.inf).astype(np.float32)
+    thr[f_in == 3] = np.exp(rng.uniform(-80, 80, int((f_in == 3).sum()))).astype(np.float32)  # log-uniform
+    thr[f_in == 4] = (rng.integers(0, 5, int((f_in == 4).sum())) * 1e-42).astype(np.float32)  # denormals, ties
+    nodes["val"][inner] = thr
+    pool = np.concatenate([thr, np.nextafter(thr, np.float32(np.inf)), np.nextafter(thr, np.float32(-np.inf)),
+                           np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 3.4e38, -3.4e38, MISSING], dtype=np.float32)])
+    data = pool[rng.integers(0, pool.size, size=(R, C))].astype(np.float32)
+    f = ta.Forest(nodes, T, D, C, missing=MISSING)
+    assert f.get_strategy(R) == ta.STRATEGY_QRING
+    f.close()
+    run_case(env, nodes, T, D, C, data, strategies=[ta.STRATEGY_QRING, ta.STRATEGY_TILERING])
