@@ -697,8 +697,10 @@ static int tilering_rows(const tahoe_forest *f)
 
 static int resolve_strategy(const tahoe_forest *f, size_t /*rows*/)
 {
-    if (f->sp) {  // sparse handle: ROWTILE = 64-row tile in LDS, DIRECT = features from global memory
+    if (f->sp) {  // sparse handle: TILEBLOCK = 64-row tile + tree tops in LDS, ROWTILE = tile only, DIRECT = neither
         if (f->strategy == TAHOE_STRATEGY_DIRECT) return TAHOE_STRATEGY_DIRECT;
+        if (f->strategy == TAHOE_STRATEGY_ROWTILE) return TAHOE_STRATEGY_ROWTILE;
+        if (sparse_top_waves(f) > 0) return TAHOE_STRATEGY_TILEBLOCK;
         return sparse_tile_fits(f) ? TAHOE_STRATEGY_ROWTILE : TAHOE_STRATEGY_DIRECT;
     }
     if (f->strategy != TAHOE_STRATEGY_AUTO) return f->strategy;
@@ -756,7 +758,7 @@ static tahoe_status launch_traversal(tahoe_forest *f, float *sums, uint32_t *lea
         // Nothing to walk: sums are zero (an empty j-loop in predict_on_cpu).
         if (sums) TAHOE_HIP_TRY(hipMemsetAsync(sums, 0, rows * sizeof(float), stream));
     } else if (f->sp) {
-        const tahoe_status ss = sparse_launch(f, sums, leaf_out, data, rows, stream, strategy == TAHOE_STRATEGY_ROWTILE);
+        const tahoe_status ss = sparse_launch(f, sums, leaf_out, data, rows, stream, strategy);
         if (ss != TAHOE_OK) return ss;
     } else if (strategy == TAHOE_STRATEGY_QRING) {
         const tahoe_status qs = qring_launch(f, sums, leaf_out, data, rows, stream, timed ? f->ev_mid[f->prof_count] : nullptr);
@@ -1102,8 +1104,11 @@ tahoe_status tahoe_forest_set_strategy(tahoe_forest *f, int strategy)
     if (strategy < TAHOE_STRATEGY_AUTO || strategy > TAHOE_STRATEGY_QRING)
         return fail(TAHOE_ERR_INVALID_ARG, "unknown strategy %d", strategy);
     if (f->sp) {
-        if (strategy > TAHOE_STRATEGY_ROWTILE || (strategy == TAHOE_STRATEGY_ROWTILE && !sparse_tile_fits(f)))
-            return fail(TAHOE_ERR_UNSUPPORTED, "a sparse forest runs AUTO, DIRECT or (when a 64-row tile fits LDS) ROWTILE");
+        if (strategy > TAHOE_STRATEGY_TILEBLOCK || (strategy == TAHOE_STRATEGY_ROWTILE && !sparse_tile_fits(f)) ||
+            (strategy == TAHOE_STRATEGY_TILEBLOCK && sparse_top_waves(f) == 0))
+            return fail(TAHOE_ERR_UNSUPPORTED,
+                        "a sparse forest runs AUTO, DIRECT, ROWTILE (a 64-row tile fits LDS) or TILEBLOCK (tile + tree tops in LDS; "
+                        "trees of <= 65536 nodes, num_cols <= 32767)");
         f->strategy = strategy;
         return TAHOE_OK;
     }

@@ -109,7 +109,8 @@ int qring_groups(const tahoe_forest *f);  // tree groups with separate quantisat
 // sparse forests (sparse.hip)
 bool sparse_tile_fits(const tahoe_forest *f);
 tahoe_status sparse_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, const float *data, size_t rows,
-                           hipStream_t stream, bool tile);
+                           hipStream_t stream, int strategy);
+int sparse_top_waves(const tahoe_forest *f);
 void sparse_destroy(tahoe_forest *f);
 void pipeline_destroy(tahoe_forest *f);
 

@@ -27,6 +27,11 @@ struct tahoe_sstate {
     int32_t *trees = nullptr;            // device: root offset per tree
     size_t num_nodes = 0;
     int max_tree_nodes = 0;
+    // compact breadth-first copy for sparse_top_kernel (null when a tree has > 65536 reachable nodes or
+    // num_cols > 32767): 8-byte nodes, every tree starts on a 16-byte boundary
+    uint2 *cnodes = nullptr;    // x = value bits; y = left_idx << 16 | def_left << 15 | fid, left_idx == 0 <=> leaf
+    int32_t *ctrees = nullptr;  // [T + 1] offsets into cnodes (even)
+    uint32_t *corig = nullptr;  // compact position -> index relative to the root in the caller's numbering
 };
 
 namespace tahoe {
@@ -102,6 +107,122 @@ __global__ void __launch_bounds__(kBlock) sparse_kernel(const tahoe_sparse_node 
     }
 }
 
+// Tree tops in LDS.  NW waves share one 64-row float32 tile and split the trees round-robin; each wave stages
+// the first kSTop nodes of its tree (breadth-first order: the top levels) into a private 4 KiB LDS slot with four
+// coalesced 16-byte loads per lane, issued before the previous tree is walked and committed after it.  A walk
+// reads nodes from the slot while its position is < kSTop and gathers from global memory below.  The gathers are
+// what bounds the plain kernel (64 lanes = 64 cache lines per step through the texture path, 12-byte nodes);
+// here only the steps below the top pay them, with 8-byte nodes.  Sums: as above, the row's owner lane adds the
+// NW leaf values of a round in tree order.
+constexpr int kSTop = 512;  // nodes per slot (8 B each)
+template <int NW, bool WRITE_LEAF>
+__global__ void __launch_bounds__(NW * 64) sparse_top_kernel(const uint2 *__restrict__ cnodes, const int32_t *__restrict__ ctrees,
+                                                             const uint32_t *__restrict__ corig, const float *__restrict__ data,
+                                                             float *__restrict__ sums, uint32_t *__restrict__ leaf_out, size_t rows,
+                                                             int cols, int num_trees, float missing, int vec4_ok)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float *tile = reinterpret_cast<float *>(smem);
+    unsigned char *slots = smem + (size_t)cols * kTileRows * sizeof(float);
+    uint2 *slot = reinterpret_cast<uint2 *>(slots + (size_t)wave * (kSTop * 8));
+    float *vals = reinterpret_cast<float *>(slots + (size_t)NW * (kSTop * 8));
+    const size_t row0 = (size_t)blockIdx.x * kTileRows;
+    const size_t row = row0 + lane;
+    const bool row_ok = row < rows;
+    const float *xrow = data + (row_ok ? row : row0) * (size_t)cols;
+    if (vec4_ok) {
+        const float4 *src4 = reinterpret_cast<const float4 *>(xrow);
+        for (int f4 = wave; f4 < cols / 4; f4 += NW) {
+            const float4 v = row_ok ? src4[f4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            tile[(4 * f4 + 0) * kTileRows + lane] = v.x;
+            tile[(4 * f4 + 1) * kTileRows + lane] = v.y;
+            tile[(4 * f4 + 2) * kTileRows + lane] = v.z;
+            tile[(4 * f4 + 3) * kTileRows + lane] = v.w;
+        }
+    } else {
+        for (int f = wave; f < cols; f += NW) tile[f * kTileRows + lane] = row_ok ? xrow[f] : 0.0f;
+    }
+    // top of tree t: uint4 j * 64 + lane holds nodes 2 * (j * 64 + lane) and the next; clamped loads stay inside
+    // the tree's (16-byte padded) node range, slots keep whatever the clamp fetched beyond it (never reached)
+    uint4 pf0, pf1, pf2, pf3;
+    auto prefetch_top = [&](int t) {
+        const int32_t lo = ctrees[t], n = ctrees[t + 1] - lo;  // n is even (padded)
+        const uint4 *src = reinterpret_cast<const uint4 *>(cnodes + lo);
+        const int last = n / 2 - 1;
+        pf0 = src[min(0 * 64 + lane, last)];
+        pf1 = src[min(1 * 64 + lane, last)];
+        pf2 = src[min(2 * 64 + lane, last)];
+        pf3 = src[min(3 * 64 + lane, last)];
+    };
+    auto commit_top = [&]() {
+        uint4 *s = reinterpret_cast<uint4 *>(slot);
+        s[0 * 64 + lane] = pf0;
+        s[1 * 64 + lane] = pf1;
+        s[2 * 64 + lane] = pf2;
+        s[3 * 64 + lane] = pf3;
+    };
+    if (wave < num_trees) prefetch_top(wave);
+    __syncthreads();  // the tile
+    constexpr int RPW = kTileRows / NW;  // rows summed by each wave's first lanes
+    float sum = 0.0f;
+    const int rounds = (num_trees + NW - 1) / NW;
+    for (int r = 0; r < rounds; ++r) {
+        const int t = r * NW + wave;
+        float v = 0.0f;
+        if (t < num_trees) {
+            commit_top();  // own slot, own wave: LDS operations of one wave complete in order
+            if (t + NW < num_trees) prefetch_top(t + NW);
+            const uint2 *root = cnodes + ctrees[t];
+            uint32_t curr = 0;
+            for (;;) {  // create() guarantees children after their parent and inside the tree: the walk terminates
+                uint2 n;
+                if (curr < (uint32_t)kSTop)
+                    n = slot[curr];
+                else
+                    n = root[curr];
+                const uint32_t left = n.y >> 16;
+                if (left == 0u) {
+                    v = __uint_as_float(n.x);
+                    break;
+                }
+                const float x = tile[(n.y & 0x7fffu) * kTileRows + lane];
+                curr = left + go_right(x, __uint_as_float(n.x), (n.y & 0x8000u) != 0u, missing);
+            }
+            if (WRITE_LEAF) {
+                if (row_ok) leaf_out[row * (size_t)num_trees + t] = corig[ctrees[t] + curr];
+            }
+        }
+        float *vb = vals + (size_t)(r & 1) * NW * kTileRows;
+        vb[wave * kTileRows + lane] = v;
+        __syncthreads();
+        if (lane < RPW) {
+            const int rr = RPW * wave + lane;
+            const int nt = min(NW, num_trees - r * NW);
+            for (int j = 0; j < nt; ++j) sum += vb[j * kTileRows + rr];  // tree order
+        }
+    }
+    if (sums && lane < RPW) {
+        const size_t orow = row0 + RPW * wave + lane;
+        if (orow < rows) sums[orow] = sum;
+    }
+}
+
+static long long sparse_top_lds(const tahoe_forest *f, int nw)
+{
+    return (long long)f->p.num_cols * kTileRows * 4 + (long long)nw * kSTop * 8 + 2LL * nw * kTileRows * 4;
+}
+
+// waves per workgroup of sparse_top_kernel for this handle; 0 = that form is unavailable
+int sparse_top_waves(const tahoe_forest *f)
+{
+    if (!f->sp || !f->sp->cnodes || f->p.num_cols < 1) return 0;
+    if (sparse_top_lds(f, 16) <= f->lds_limit) return 16;
+    if (sparse_top_lds(f, 8) <= f->lds_limit) return 8;
+    return 0;
+}
+
 static long long sparse_lds(const tahoe_forest *f, bool tile)
 {
     return (tile ? (long long)f->p.num_cols * kTileRows * 4 : 0) + 2LL * kWaves * kTileRows * 4;
@@ -110,11 +231,34 @@ static long long sparse_lds(const tahoe_forest *f, bool tile)
 bool sparse_tile_fits(const tahoe_forest *f) { return f->p.num_cols >= 1 && sparse_lds(f, true) <= f->lds_limit; }
 
 tahoe_status sparse_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, const float *data, size_t rows,
-                           hipStream_t stream, bool tile)
+                           hipStream_t stream, int strategy)
 {
     const tahoe_sstate *sp = f->sp;
     const unsigned grid = (unsigned)((rows + kTileRows - 1) / kTileRows);
     const int vec4_ok = (f->p.num_cols % 4 == 0) && ((reinterpret_cast<uintptr_t>(data) & 15u) == 0);
+    if (strategy == TAHOE_STRATEGY_TILEBLOCK) {
+        const int nw = sparse_top_waves(f);
+        if (nw == 0) return fail(TAHOE_ERR_UNSUPPORTED, "sparse TILEBLOCK: the compact form or its LDS tile is unavailable");
+        const int lds = (int)sparse_top_lds(f, nw);
+#define TAHOE_SPARSE_TOP(NW_, LEAF_)                                                                                     \
+    hipLaunchKernelGGL((sparse_top_kernel<NW_, LEAF_>), dim3(grid), dim3(NW_ * 64), lds, stream, sp->cnodes, sp->ctrees, \
+                       sp->corig, data, sums, leaf_out, rows, f->p.num_cols, f->p.num_trees, f->p.missing, vec4_ok)
+        if (nw == 16) {
+            if (leaf_out)
+                TAHOE_SPARSE_TOP(16, true);
+            else
+                TAHOE_SPARSE_TOP(16, false);
+        } else {
+            if (leaf_out)
+                TAHOE_SPARSE_TOP(8, true);
+            else
+                TAHOE_SPARSE_TOP(8, false);
+        }
+#undef TAHOE_SPARSE_TOP
+        TAHOE_HIP_TRY(hipGetLastError());
+        return TAHOE_OK;
+    }
+    const bool tile = strategy == TAHOE_STRATEGY_ROWTILE;
     const int lds = (int)sparse_lds(f, tile);
 #define TAHOE_SPARSE_LAUNCH(TILE_, LEAF_)                                                                            \
     hipLaunchKernelGGL((sparse_kernel<TILE_, LEAF_>), dim3(grid), dim3(kBlock), lds, stream, sp->nodes, sp->trees, data, \
@@ -140,6 +284,9 @@ void sparse_destroy(tahoe_forest *f)
     if (!f->sp) return;
     if (f->sp->nodes) (void)hipFree(f->sp->nodes);
     if (f->sp->trees) (void)hipFree(f->sp->trees);
+    if (f->sp->cnodes) (void)hipFree(f->sp->cnodes);
+    if (f->sp->ctrees) (void)hipFree(f->sp->ctrees);
+    if (f->sp->corig) (void)hipFree(f->sp->corig);
     delete f->sp;
     f->sp = nullptr;
 }
@@ -225,6 +372,62 @@ tahoe_status tahoe_sparse_forest_create(tahoe_forest **out, const int32_t *trees
             return bail(e, "hipFuncSetAttribute(sparse)");
         if ((e = allow_max_lds(reinterpret_cast<const void *>(&sparse_kernel<true, true>), f->lds_limit)) != hipSuccess)
             return bail(e, "hipFuncSetAttribute(sparse)");
+    }
+    // ---- compact breadth-first copy (sparse_top_kernel) ----
+    if (p->num_cols <= 32767 && p->num_trees > 0) {
+        std::vector<uint2> cn;
+        std::vector<uint32_t> orig;
+        std::vector<int32_t> ct((size_t)p->num_trees + 1, 0);
+        std::vector<uint32_t> order, newpos;
+        bool ok = true;
+        for (int t = 0; t < p->num_trees && ok; ++t) {
+            const long long lo = trees[t], hi = (t + 1 < p->num_trees) ? trees[t + 1] : p->num_nodes;
+            const tahoe_sparse_node *tn = nodes + lo;
+            // breadth-first order of the reachable nodes; a child pair stays adjacent
+            order.assign(1, 0u);
+            for (size_t q = 0; q < order.size() && order.size() <= 65536; ++q) {
+                const tahoe_sparse_node &n = tn[order[q]];
+                if (n.bits & kSIsLeaf) continue;
+                order.push_back((uint32_t)n.left_idx);
+                order.push_back((uint32_t)n.left_idx + 1u);
+            }
+            if (order.size() > 65536) {
+                ok = false;
+                break;
+            }
+            newpos.assign((size_t)(hi - lo), 0u);
+            for (size_t q = 0; q < order.size(); ++q) newpos[order[q]] = (uint32_t)q;
+            ct[(size_t)t] = (int32_t)cn.size();
+            for (size_t q = 0; q < order.size(); ++q) {
+                const tahoe_sparse_node &n = tn[order[q]];
+                uint2 c;
+                memcpy(&c.x, &n.val, 4);
+                if (n.bits & kSIsLeaf)
+                    c.y = 0u;
+                else  // the left child of any node sits at a position >= 1: 0 marks a leaf
+                    c.y = (newpos[(size_t)n.left_idx] << 16) | ((n.bits & kSDefLeft) ? 0x8000u : 0u) | (uint32_t)(n.bits & kSFidMask);
+                cn.push_back(c);
+                orig.push_back(order[q]);
+            }
+            if (cn.size() & 1) {  // next tree starts on a 16-byte boundary
+                cn.push_back(make_uint2(0u, 0u));
+                orig.push_back(0u);
+            }
+            if (cn.size() > 0x7fffffffu) ok = false;
+        }
+        if (ok) {
+            ct[(size_t)p->num_trees] = (int32_t)cn.size();
+            if ((e = hipMalloc(reinterpret_cast<void **>(&sp->cnodes), cn.size() * sizeof(uint2))) != hipSuccess) return bail(e, "hipMalloc(cnodes)");
+            if ((e = hipMalloc(reinterpret_cast<void **>(&sp->ctrees), ct.size() * sizeof(int32_t))) != hipSuccess) return bail(e, "hipMalloc(ctrees)");
+            if ((e = hipMalloc(reinterpret_cast<void **>(&sp->corig), orig.size() * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMalloc(corig)");
+            if ((e = hipMemcpy(sp->cnodes, cn.data(), cn.size() * sizeof(uint2), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(cnodes)");
+            if ((e = hipMemcpy(sp->ctrees, ct.data(), ct.size() * sizeof(int32_t), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(ctrees)");
+            if ((e = hipMemcpy(sp->corig, orig.data(), orig.size() * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(corig)");
+            f->device_bytes += cn.size() * sizeof(uint2) + ct.size() * sizeof(int32_t) + orig.size() * sizeof(uint32_t);
+            for (const void *k : {(const void *)&sparse_top_kernel<16, false>, (const void *)&sparse_top_kernel<16, true>,
+                                  (const void *)&sparse_top_kernel<8, false>, (const void *)&sparse_top_kernel<8, true>})
+                if ((e = allow_max_lds(k, f->lds_limit)) != hipSuccess) return bail(e, "hipFuncSetAttribute(sparse_top)");
+        }
     }
     *out = f;
     return TAHOE_OK;

@@ -420,3 +420,34 @@ def test_quantiser_on_skewed_thresholds(env, monkeypatch, buckets):
     assert f.get_strategy(R) == ta.STRATEGY_QRING
     f.close()
     run_case(env, nodes, T, D, C, data, strategies=[ta.STRATEGY_QRING, ta.STRATEGY_TILERING])
+
+
+def test_predict_is_capturable_in_a_hip_graph(env):
+    """A predict on a reserved handle is a fixed sequence of stream operations (a memset, the quantise and walk
+    kernels, the output transform): no allocation, no synchronisation.  It can therefore be captured into a
+    hipGraph once and replayed -- the way a launch-bound caller (K1: 10 k rows, three launches per batch) removes
+    the per-launch host cost.  Replays must give the oracle's bits, also after the input buffer changes."""
+    ta, oracle, torch = env
+    T, D, C, R = 120, 8, 18, 10_000
+    nodes = ta.synth_forest(T, D, C, seed=91, leaf_prob=0.05)
+    f = ta.Forest(nodes, T, D, C, missing=MISSING, output=ta.OUT_AVG | ta.OUT_SIGMOID, global_bias=0.1)
+    f.reserve(R)
+    x = torch.empty((R, C), dtype=torch.float32, device="cuda")
+    out = torch.zeros(R, dtype=torch.float32, device="cuda")
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.graph(graph, stream=side):
+        f.predict(x, out, stream=torch.cuda.current_stream())
+    for seed in (92, 93):
+        data = ta.synth_data(R, C, seed=seed, missing_prob=0.05, missing=MISSING)
+        x.copy_(torch.from_numpy(data))
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        f.check()
+        want = oracle.predict(nodes, T, D, data, MISSING, output=ta.OUT_AVG | ta.OUT_SIGMOID, global_bias=0.1, threads=8)[0]
+        got = out.cpu().numpy()
+        assert np.allclose(got, want, rtol=1e-6, atol=0), seed  # sigmoid: device expf vs glibc expf
+        eager = f.predict(x).cpu().numpy()
+        assert np.array_equal(bits(got), bits(eager)), seed     # replay == eager launch, bit for bit
+    f.close()

@@ -79,7 +79,18 @@ def test_sparse_walk_on_gpu(ta):
         f = ta.capi.SparseForest(sn_, tr_, cols, missing=MISSING)
         assert f.info().is_sparse == 1
         x = torch.from_numpy(data_).cuda()
-        for strategy in (ta.STRATEGY_AUTO, ta.STRATEGY_DIRECT):
+        strategies = [ta.STRATEGY_AUTO, ta.STRATEGY_DIRECT]
+        for extra in (ta.STRATEGY_ROWTILE, ta.STRATEGY_TILEBLOCK):  # tile in LDS / tile + tree tops in LDS
+            try:
+                f.set_strategy(extra)
+                strategies.append(extra)
+            except ta.TahoeError as err:
+                assert err.status == 7 and cols > 512  # unavailable only when the tile does not fit
+        if cols <= 512:
+            assert ta.STRATEGY_TILEBLOCK in strategies
+            f.set_strategy(ta.STRATEGY_AUTO)
+            assert f.get_strategy(len(data_)) == ta.STRATEGY_TILEBLOCK
+        for strategy in strategies:
             f.set_strategy(strategy)
             leaf, sums = f.predict_leaf_idx(x)
             raw = f.predict_raw(x)
@@ -89,6 +100,22 @@ def test_sparse_walk_on_gpu(ta):
             assert np.array_equal(raw.cpu().numpy().view(np.uint32), want.view(np.uint32))
         with pytest.raises(ta.TahoeError):
             f.set_strategy(ta.STRATEGY_QRING)
+    # hand-made: a root that is a leaf, a 3-node tree, an orphan pair nobody links to, fewer trees than waves
+    nd = np.zeros(8, dtype=sn.dtype)
+    LEAF = np.int32(-2**31)
+    nd["val"][:] = [7.0, 0.5, -1.0, 2.0, 100.0, 200.0, 3.0, 0.0]
+    nd["bits"][:] = [LEAF, 1, LEAF, LEAF, LEAF, LEAF, LEAF, LEAF]  # tree 1 splits on feature 1 at 0.5
+    nd["left_idx"][:] = [0, 1, 0, 0, 0, 0, 0, 0]
+    roots = np.array([0, 1, 6], dtype=np.int32)  # tree 1 = nodes 1..5 (4, 5 unreachable), tree 2 = nodes 6..7
+    xs = np.array([[0.0, 0.4], [0.0, 0.5], [0.0, np.nan], [0.0, MISSING]], dtype=np.float32)
+    want, want_leaf = oracle.sparse_predict(nd, roots, xs, MISSING, want_leaf=True)
+    assert want.tolist() == [9.0, 12.0, 9.0, 12.0]  # 7 + (x1 >= 0.5 or missing&!def_left ? 2 : -1) + 3
+    f = ta.capi.SparseForest(nd, roots, 2, missing=MISSING)
+    for strategy in (ta.STRATEGY_TILEBLOCK, ta.STRATEGY_ROWTILE, ta.STRATEGY_DIRECT):
+        f.set_strategy(strategy)
+        leaf, sums = f.predict_leaf_idx(torch.from_numpy(xs).cuda())
+        assert np.array_equal(sums.cpu().numpy().view(np.uint32), want.view(np.uint32))
+        assert np.array_equal(leaf.cpu().numpy().view(np.uint32), want_leaf)
     # malformed forests are rejected (the reference would walk out of the arrays or spin)
     bad = sn.copy()
     first_inner = int(np.flatnonzero((bad["bits"].view(np.uint32) >> 31) == 0)[0])

@@ -105,6 +105,14 @@ def main():
     sn, tr = ta.capi.synth_sparse_forest(T, C, 4, 24, 0.32, 65535, 44)
     f = ta.capi.SparseForest(sn, tr, C, missing=MISSING)
     x = torch.from_numpy(data[:R].copy()).cuda()
+    per_strategy = {}
+    for sid in (ta.STRATEGY_DIRECT, ta.STRATEGY_ROWTILE, ta.STRATEGY_TILEBLOCK):
+        try:
+            f.set_strategy(sid)
+        except ta.TahoeError:
+            continue
+        per_strategy[ta.STRATEGY_NAMES[sid]] = round(time_predict(f, x, steps=2, warmup=1)[0], 3)
+    f.set_strategy(ta.STRATEGY_AUTO)
     ms, _ = time_predict(f, x, steps=2, warmup=1)
     sample = np.arange(0, R, 400)
     want, want_leaf = oracle.sparse_predict(sn, tr, data[:R][sample], MISSING, want_leaf=True, threads=16)
@@ -113,7 +121,7 @@ def main():
     sizes = np.diff(np.append(tr, sn.size))
     res["K5"] = {"shape": {"trees": T, "cols": C, "rows": R, "nodes": int(sn.size), "nodes_per_tree_mean": float(sizes.mean()),
                            "nodes_per_tree_max": int(sizes.max())},
-                 "strategy": "sparse_" + ta.STRATEGY_NAMES[f.get_strategy(R)], "ms": round(ms, 3), "samples_per_s": round(R / ms * 1e3),
+                 "strategy": "sparse_" + ta.STRATEGY_NAMES[f.get_strategy(R)], "ms": round(ms, 3), "ms_per_strategy": per_strategy, "samples_per_s": round(R / ms * 1e3),
                  "parity_sample_%d" % sample.size: bool(np.array_equal(bits(leaf.cpu().numpy()), want_leaf)
                                                          and np.array_equal(bits(sums.cpu().numpy()), bits(want)))}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
