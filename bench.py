@@ -51,6 +51,9 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=100_000, help="rows of the batch timed on the CPU oracle")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-host", action="store_true", help="skip the host-resident (PCIe-inclusive) leg")
+    ap.add_argument("--no-tree-leg", action="store_true",
+                    help="skip the secondary K4 leg (8000 trees split across the ranks + one RCCL all-reduce per batch)")
+    ap.add_argument("--tree-leg-trees", type=int, default=8000)
     args = ap.parse_args()
 
     import torch
@@ -68,7 +71,9 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        import datetime
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=300))
 
     T, D, C, R = args.trees, args.depth, args.cols, args.rows
     nodes = ta.synth_forest(T, D, C, seed=42)
@@ -152,6 +157,50 @@ def main():
                                  / HBM_PEAK_GBPS, 5),
     }
 
+    # ---- secondary leg: BASELINE config 4 ("K4"), the forest north_star shards by trees.  Every rank holds
+    # trees [T4*rank/N, T4*(rank+1)/N) and the same 1M rows; per batch: partial float32 sums, ONE all-reduce of
+    # 4 B/row over RCCL/xGMI, transform on the total.  Strong scaling; reported beside `value`, never as it. ----
+    tree_leg = None
+    if not args.no_tree_leg and not (world > 1 and args.shard == "trees") and (T, D, C, R) == (1000, 12, 256, 1_000_000):
+        try:
+            T4 = args.tree_leg_trees
+            lo4, hi4 = (T4 * rank) // world, (T4 * (rank + 1)) // world
+            # counter-based generator: tree t is the same on every rank; a rank keeps its slice
+            nodes4 = ta.synth_forest(T4, D, C, seed=45)[lo4 * n_per_tree: hi4 * n_per_tree].copy()
+            x4 = x if rank == 0 and first_row == 0 else torch.from_numpy(ta.synth_data(R, C, seed=43, first_row=0)).cuda()
+            f4 = ta.Forest(nodes4, hi4 - lo4, D, C, missing=MISSING)
+            f4.reserve(R)
+            p4 = torch.empty(R, dtype=torch.float32, device="cuda")
+
+            def step4():
+                f4.predict_raw(x4, p4, stream=stream)
+                if world > 1:
+                    dist.all_reduce(p4)
+                ta.capi.transform_preds(p4, 0, T4, 0.0, 0.0, stream=stream)
+
+            k4, w4 = max(3, min(args.steps, 10)), 2
+            for _ in range(w4):
+                step4()
+            fence()
+            t4 = time.perf_counter()
+            for _ in range(k4):
+                step4()
+            fence()
+            t4 = time.perf_counter() - t4
+            if world > 1:
+                tt = torch.tensor([t4], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                t4 = float(tt.item())
+            tree_leg = {"workload": f"K4: {T4} trees depth {D}, {C} features, {R} rows; trees split across {world} GPU(s), "
+                                    f"one all-reduce of {4 * R} B per batch", "scaling": "strong",
+                        "value": round(R / (t4 / k4), 1), "unit": "samples/s", "ms_per_step": round(t4 / k4 * 1e3, 4),
+                        "steps": k4, "trees_per_gpu": hi4 - lo4, "tree_groups_per_gpu": f4.info().qring_groups,
+                        "bit_exact": world == 1}
+            f4.close()
+            del x4, p4
+        except Exception as err:  # the primary line must survive a failure of the secondary leg
+            tree_leg = {"error": f"{type(err).__name__}: {err}"}
+
     # ---- host-resident batch (rank 0, N = 1 only): the PCIe-inclusive rate, reported beside `value`, never as it ----
     host_leg = None
     if rank == 0 and world == 1 and not args.no_host:
@@ -220,6 +269,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "host_pipeline": host_leg,
+            "tree_sharded_k4": tree_leg,
         }
         print(json.dumps(out), flush=True)
     if world > 1:
