@@ -451,3 +451,31 @@ def test_predict_is_capturable_in_a_hip_graph(env):
         eager = f.predict(x).cpu().numpy()
         assert np.array_equal(bits(got), bits(eager)), seed     # replay == eager launch, bit for bit
     f.close()
+
+
+def test_fuzz_shapes_against_the_oracle(env):
+    """Seeded random shapes (trees, depth, columns on both sides of 256 / 512 and odd, rows around tile and chunk
+    multiples, early-leaf and missing / NaN rates), every available strategy, dense and converted-to-sparse:
+    leaf indices and float32 sums must equal the oracle's bits in every case."""
+    ta, oracle, torch = env
+    rng = np.random.default_rng(2026)
+    for case in range(40):
+        T = int(rng.integers(1, 90))
+        D = int(rng.integers(0, 12))
+        C = int(rng.choice([1, 2, 3, 7, 16, 31, 64, 255, 256, 257, 300, 511, 512, 513, 700]))
+        R = int(rng.choice([1, 63, 64, 65, 127, 128, 129, 255, 1000, 4097]))
+        leaf_prob = float(rng.choice([0.0, 0.0, 0.1, 0.4]))
+        miss = float(rng.choice([0.0, 0.0, 0.05, 0.5]))
+        nanp = float(rng.choice([0.0, 0.02]))
+        nodes = ta.synth_forest(T, D, C, seed=1000 + case, leaf_prob=leaf_prob)
+        data = ta.synth_data(R, C, seed=2000 + case, missing_prob=miss, missing=MISSING, nan_prob=nanp)
+        want, want_leaf = run_case(env, nodes, T, D, C, data)
+        if case % 4 == 0:  # the same forest through the sparse format
+            sn, tr = ta.capi.dense_to_sparse(nodes, T, D)
+            sw, sl = oracle.sparse_predict(sn, tr, data, MISSING, want_leaf=True)
+            assert np.array_equal(bits(sw), bits(want)), case
+            f = ta.capi.SparseForest(sn, tr, C, missing=MISSING)
+            leaf, sums = f.predict_leaf_idx(torch.from_numpy(data).cuda())
+            assert np.array_equal(bits(sums.cpu().numpy()), bits(want)), case
+            assert np.array_equal(bits(leaf.cpu().numpy()), sl), case
+            f.close()
