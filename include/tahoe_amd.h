@@ -207,6 +207,8 @@ typedef struct {
     int is_sparse;           /* 1: handle made by tahoe_sparse_forest_create (only the generic fields are set) */
     int ring_rows;           /* rows per TILERING tile: 64, 128, or 0 = strategy unavailable */
     int tilering_lds_bytes;  /* dynamic LDS of the TILERING kernel */
+    int qring_tile_rows;     /* rows per quantised tile in LDS: 128, or 64 / 32 / 16 for wide rows (several trees per
+                              * wave); 0 = features read from the quantised tile in L2, or QRING unavailable */
 } tahoe_forest_info;
 tahoe_status tahoe_forest_get_info(const tahoe_forest *f, tahoe_forest_info *info);
 

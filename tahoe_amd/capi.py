@@ -87,6 +87,7 @@ class ForestInfo(C.Structure):
         ("is_sparse", C.c_int),
         ("ring_rows", C.c_int),
         ("tilering_lds_bytes", C.c_int),
+        ("qring_tile_rows", C.c_int),
     ]
 
 

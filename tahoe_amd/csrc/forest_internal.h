@@ -104,6 +104,8 @@ long long qring_lds_bytes(const tahoe_forest *f);
 tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, const float *data, size_t rows,
                           hipStream_t stream, hipEvent_t mid_event);
 tahoe_status qring_reserve(tahoe_forest *f, size_t rows);
+int qwide_rows(const tahoe_forest *f);   // rows per tile of the wide-row form; 0 = not used
+bool qring_lds_tile(const tahoe_forest *f);
 int qring_groups(const tahoe_forest *f);  // tree groups with separate quantisation (1 for most forests)
 
 // sparse forests (sparse.hip)

@@ -63,6 +63,8 @@ struct tahoe_qstate {
     bool have_mid = false;        // De - 2 > top_levels: heap of quantised nodes for the middle levels
     int top_stride = 0;           // u32 entries per tree in `top` (>= 4)
     bool narrow = false;          // node words in the NARROW layout (num_cols <= 256, 15 walkers, LDS tile)
+    int wide_rt = 0;              // rows per tile of the wide-row form (qwide_kernel), fixed at create; 0 = not used
+    int wide_lw = 0;              // ... and the top levels its LDS slots hold
     std::vector<tahoe_qgroup> groups;
     uint16_t *xq = nullptr;       // workspace: quantised tiles (re-used by every group)
     size_t xq_rows = 0;           // rows the workspace holds
@@ -85,6 +87,13 @@ constexpr uint32_t kCodeMissing = 0xFFFFu;
 // position of tile row r (0..127) inside a feature column of 128 u16: within a 32-lane group the
 // rows land in 32 different LDS banks (two rows per dword come from different groups)
 __host__ __device__ __forceinline__ int qrow_pos(int r) { return ((r & 31) << 1) | ((r >> 5) & 1) | ((r >> 6) << 6); }
+// index of (row r, feature f) in the quantised workspace: tiles of 2^trs rows, xq[tile][f][2^trs]; 128-row tiles
+// permute the rows inside a column (qrow_pos), the smaller tiles of the wide-row form keep them in order
+__device__ __forceinline__ size_t q_tile_index(size_t r, int f, int cols, int trs)
+{
+    const int rr = (int)(r & (((size_t)1 << trs) - 1));
+    return (((r >> trs) * (size_t)cols + (size_t)f) << trs) + (size_t)(trs == 7 ? qrow_pos(rr) : rr);
+}
 
 // ------------------------------------------------------------------------------------------------
 // (1) float32 rows -> u16 codes.  One workgroup = F adjacent features x kQuantRowsPerBlock rows, the F
@@ -108,7 +117,7 @@ template <int F>
 __global__ void __launch_bounds__(kQuantThreads) quantize_kernel(const float *__restrict__ data, const float *__restrict__ tables,
                                                                  const int *__restrict__ offsets, uint16_t *__restrict__ xq,
                                                                  uint32_t *__restrict__ chunk_flags, size_t rows, int cols,
-                                                                 float missing, int tab_stride)
+                                                                 float missing, int tab_stride, int trs)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *tab = reinterpret_cast<float *>(smem);
@@ -166,7 +175,7 @@ __global__ void __launch_bounds__(kQuantThreads) quantize_kernel(const float *__
                     const bool ms = fabsf(x[u] - missing) <= kMissingEps;
                     saw_missing |= ms;
                     const uint32_t code = ms ? kCodeMissing : (uint32_t)(cnt[u] - size[j]);
-                    xq[(r / kQRows) * ((size_t)cols * kQRows) + (size_t)(f0 + j) * kQRows + qrow_pos((int)(r % kQRows))] =
+                    xq[q_tile_index(r, f0 + j, cols, trs)] =
                         (uint16_t)code;
                 }
             }
@@ -184,7 +193,7 @@ constexpr int kQuantPairThreads = 1024;
 __global__ void __launch_bounds__(kQuantPairThreads)
     quantize_pair_kernel(const float *__restrict__ data, const float *__restrict__ tables, const int *__restrict__ offsets,
                          uint16_t *__restrict__ xq, uint32_t *__restrict__ chunk_flags, size_t rows, int cols, float missing,
-                         int lds_floats)
+                         int lds_floats, int trs)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *tab = reinterpret_cast<float *>(smem);
@@ -235,7 +244,7 @@ __global__ void __launch_bounds__(kQuantPairThreads)
             for (int u = 0; u < U; ++u) {
                 const size_t r = rb + (size_t)u * blockDim.x;
                 if (r < r1) {
-                    uint16_t *dst = xq + (r / kQRows) * ((size_t)cols * kQRows) + (size_t)f0 * kQRows + qrow_pos((int)(r % kQRows));
+                    uint16_t *dst = xq + q_tile_index(r, f0, cols, trs);
                     if (do0) {
                         const bool ms = fabsf(xv[u].x - missing) <= kMissingEps;
                         saw_missing |= ms;
@@ -244,7 +253,7 @@ __global__ void __launch_bounds__(kQuantPairThreads)
                     if (do1) {
                         const bool ms = fabsf(xv[u].y - missing) <= kMissingEps;
                         saw_missing |= ms;
-                        dst[kQRows] = (uint16_t)(ms ? kCodeMissing : (uint32_t)(c1[u] - size1));
+                        dst[(size_t)1 << trs] = (uint16_t)(ms ? kCodeMissing : (uint32_t)(c1[u] - size1));
                     }
                 }
             }
@@ -284,7 +293,7 @@ __global__ void __launch_bounds__(kQuantPairThreads)
     quantize_bucket_pair_kernel(const float *__restrict__ data, const float *__restrict__ bsorted, const int *__restrict__ boffsets,
                                 const uint16_t *__restrict__ bstarts, const float4 *__restrict__ bparams,
                                 uint16_t *__restrict__ xq, uint32_t *__restrict__ chunk_flags, size_t rows, int cols, float missing,
-                                int B)
+                                int B, int trs)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned nblk = gridDim.x;
@@ -358,11 +367,11 @@ __global__ void __launch_bounds__(kQuantPairThreads)
         for (int u = 0; u < U; ++u) {
             const size_t r = rb + (size_t)u * blockDim.x;
             if (r < r1) {
-                uint16_t *dst = xq + (r / kQRows) * ((size_t)cols * kQRows) + (size_t)f0 * kQRows + qrow_pos((int)(r % kQRows));
+                uint16_t *dst = xq + q_tile_index(r, f0, cols, trs);
                 const bool ms0 = fabsf(xv[u].x - missing) <= kMissingEps, ms1 = fabsf(xv[u].y - missing) <= kMissingEps;
                 saw_missing |= ms0 | ms1;
                 dst[0] = (uint16_t)(ms0 ? kCodeMissing : (uint32_t)c0[u]);
-                dst[kQRows] = (uint16_t)(ms1 ? kCodeMissing : (uint32_t)c1[u]);
+                dst[(size_t)1 << trs] = (uint16_t)(ms1 ? kCodeMissing : (uint32_t)c1[u]);
             }
         }
     }
@@ -418,9 +427,10 @@ __device__ __forceinline__ uint32_t q_descend(uint32_t i, uint64_t right_mask)
 // the quantised tile in global memory (L2-resident: one 128-row tile of 3072 columns is 768 KiB); `gx` = the
 // tile's base, posb = byte position inside a column.
 typedef const uint16_t __attribute__((address_space(3))) *lds_u16_ptr;
-template <bool LDSX, bool NARROW>
+template <bool LDSX, bool NARROW, int CSHIFT = 8>
 __device__ __forceinline__ uint32_t q_xread(const unsigned char *gx, uint32_t node, uint32_t posb)
 {
+    static_assert(!NARROW || CSHIFT == 8, "the NARROW layout is defined for 256-byte feature columns");
     if (LDSX && NARROW) {
         // the tile starts at LDS address 0 (checked at kernel entry) and posb < 256: address = node[15:8] : posb[7:0]
         uint32_t addr;
@@ -429,11 +439,11 @@ __device__ __forceinline__ uint32_t q_xread(const unsigned char *gx, uint32_t no
     }
     if (LDSX) {
         uint32_t addr;  // asm: hipcc re-canonicalises the C form into shift + and + add
-        asm("v_bfe_u32 %0, %1, 16, 15\n\tv_lshl_add_u32 %0, %0, 8, %2" : "=&v"(addr) : "v"(node), "v"(posb));
+        asm("v_bfe_u32 %0, %1, 16, 15\n\tv_lshl_add_u32 %0, %0, %3, %2" : "=&v"(addr) : "v"(node), "v"(posb), "n"(CSHIFT));
         return *reinterpret_cast<lds_u16_ptr>(addr);
     }
     if (NARROW) return *reinterpret_cast<const uint16_t *>(gx + (node & 0xFF00u) + posb);
-    return *reinterpret_cast<const uint16_t *>(gx + (((node >> 16) & 0x7fffu) << 8) + posb);
+    return *reinterpret_cast<const uint16_t *>(gx + (((node >> 16) & 0x7fffu) << CSHIFT) + posb);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -668,6 +678,196 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
 }
 
 // ------------------------------------------------------------------------------------------------
+// (3) the walk for wide rows ("QWIDE").  When num_cols is too large for a 128-row u16 tile in LDS (K2: 3072
+// columns = 768 KiB) the tile shrinks to RT = 64 / 32 / 16 rows and a walker wave walks TPW = 64 / RT trees at
+// once: lane = (tree slot j, row r).  Everything else is the scheme above -- private top slots (TPW small tops per
+// wave), 32-byte bottom blocks gathered one group ahead, a consumer wave adding leaf values in tree order through
+// an LDS ring -- so the sums stay bit-identical.  (The alternative, 128-row tiles read from L2 -- the GX form --
+// thrashes: 32 workgroups per XCD x 768 KiB against a 4 MiB L2.)  Tiles are xq[tile][fid][RT] u16, rows in order.
+// Tops: the first 2^LW heap entries of each tree's `top` array, LW = min(top_levels, log2(1024 / TPW)): a 4 KiB slot
+// per wave; levels LW .. De-3 come from the quantised heap in global memory (qinner).
+constexpr int kWideRingBytes = 8192;
+template <int RT, bool WRITE_LEAF>
+__global__ void __launch_bounds__(16 * 64)
+    qwide_kernel(const uint16_t *__restrict__ xq, const uint32_t *__restrict__ top, const uint4 *__restrict__ blocks,
+                 const uint32_t *__restrict__ qinner, const uint32_t *__restrict__ leaf_orig, float *__restrict__ sums,
+                 uint32_t *__restrict__ leaf_out, size_t rows, int cols, int num_trees, int depth, int top_levels,
+                 int top_stride, const uint32_t *__restrict__ chunk_flags, int *__restrict__ error_flag,
+                 const float *__restrict__ sums_in, int tree_base, int total_trees, int slot_bytes, int lw)
+{
+    constexpr int NWALK = 15;
+    constexpr int NT = (NWALK + 1) * 64;
+    constexpr int TPW = 64 / RT;                       // trees a walker wave walks at once
+    constexpr int RE = kWideRingBytes / (RT * 4);      // ring entries (trees): >= two rounds of NWALK * TPW
+    constexpr int NBATCH = RE / 2;                     // trees the consumer takes per poll (<= 64)
+    constexpr int CSHIFT = RT == 64 ? 7 : RT == 32 ? 6 : 5;  // log2 of a feature column's bytes
+    static_assert(NBATCH <= 64 && RE >= 2 * NWALK * TPW, "ring too small");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint16_t *tile = reinterpret_cast<uint16_t *>(smem);
+    unsigned char *slots = smem + (size_t)cols * RT * sizeof(uint16_t);
+    float *ring_vals = reinterpret_cast<float *>(slots + (size_t)NWALK * slot_bytes);  // slot = TPW tops, <= 4 KiB
+    uint32_t *ring_ready = reinterpret_cast<uint32_t *>(ring_vals + RE * RT);
+    uint32_t *consumed = ring_ready + RE;
+    const size_t row0 = (size_t)blockIdx.x * RT;
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(xq + (size_t)blockIdx.x * ((size_t)cols * RT));
+        uint4 *dst = reinterpret_cast<uint4 *>(tile);
+        const int n16 = cols * RT * 2 / 16;
+        for (int e = tid; e < n16; e += NT) dst[e] = src[e];
+    }
+    for (int e = tid; e < RE; e += NT) ring_ready[e] = 0u;
+    if (tid == 0) *consumed = 0u;
+
+    if (wave == NWALK) {
+        // ================= consumer: ordered accumulation, lane = row =================
+        __syncthreads();
+        const size_t irow = row0 + lane;
+        float sum = (sums_in && lane < RT && irow < rows) ? sums_in[irow] : 0.0f;
+        bool dead = false;
+        for (int t0 = 0; t0 < num_trees && !dead; t0 += NBATCH) {
+            const int nb = min(NBATCH, num_trees - t0);
+            int spins = 0;
+            for (;;) {
+                const bool ok = lane >= nb || lds_flag_load(&ring_ready[(t0 + lane) % RE]) == (uint32_t)(t0 + lane + 1);
+                if (__ballot(ok) == ~0ull) break;
+                if (++spins > kQSpinLimit) {
+                    dead = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (dead) break;
+            asm volatile("" ::: "memory");  // the values are read after the flags
+            if (lane < RT)
+                for (int j = 0; j < nb; ++j) sum += ring_vals[((t0 + j) % RE) * RT + lane];  // tree order
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) lds_flag_store(consumed, (uint32_t)(t0 + nb));
+        }
+        if (dead && lane == 0) atomicOr(error_flag, 1);
+        if (sums && lane < RT && irow < rows) sums[irow] = sum;
+        return;
+    }
+
+    // ================= walkers =================
+    const int j = lane / RT, r = lane % RT;           // tree slot, row of the tile
+    // lw (<= min(top_levels, LWMAX), chosen at create so that tile + slots fit): levels served from the LDS slot
+    const int cpt = max(1, (1 << lw) >> 2);           // 16-byte chunks per staged top (top_stride >= 4 entries)
+    unsigned char *wslot = slots + (size_t)wave * slot_bytes;
+    const uint32_t *slot = reinterpret_cast<const uint32_t *>(wslot + (size_t)j * cpt * 16);
+    const int n_groups = (num_trees + TPW - 1) / TPW;
+    uint4 pf0 = {}, pf1 = {}, pf2 = {}, pf3 = {};
+    // chunk c of the wave's slot = chunk (c % cpt) of tree g * TPW + c / cpt (clamped: in bounds, branch-free)
+    auto prefetch_tops = [&](int g) {
+        auto ld = [&](int c) {
+            c = min(c, TPW * cpt - 1);
+            const int t = min(g * TPW + c / cpt, num_trees - 1);
+            return reinterpret_cast<const uint4 *>(top + (size_t)t * top_stride)[c % cpt];
+        };
+        pf0 = ld(0 * 64 + lane);
+        pf1 = ld(1 * 64 + lane);
+        pf2 = ld(2 * 64 + lane);
+        pf3 = ld(3 * 64 + lane);
+    };
+    auto commit_tops = [&]() {  // TPW * cpt <= 256 chunks; clamped lanes rewrite the last chunk with its own value
+        uint4 *s = reinterpret_cast<uint4 *>(wslot);
+        const int last = TPW * cpt - 1;
+        s[min(0 * 64 + lane, last)] = pf0;
+        s[min(1 * 64 + lane, last)] = pf1;
+        s[min(2 * 64 + lane, last)] = pf2;
+        s[min(3 * 64 + lane, last)] = pf3;
+    };
+    if (wave < n_groups) {
+        prefetch_tops(wave);
+        commit_tops();
+    }
+    __syncthreads();
+
+    bool dead = false;
+    auto run = [&](auto ms_tag) {
+        constexpr bool MS = decltype(ms_tag)::value;
+        const uint32_t pos = (uint32_t)reinterpret_cast<uintptr_t>(tile) + 2u * (uint32_t)r;
+        const size_t n_inner = ((size_t)1 << depth) - 1;
+        const uint32_t n_blocks = 1u << (depth - 2);
+        const uint32_t first_block_node = n_blocks - 1;
+        const size_t row = row0 + r;
+        auto finish = [&](int g, const uint4 &na, const uint4 &nb, uint32_t bs) {
+            const int t = g * TPW + j;
+            const bool c0 = q_go_right<MS, false>(q_xread<true, false, CSHIFT>(nullptr, na.x, pos), na.x);
+            const uint32_t n1 = c0 ? na.z : na.y;
+            const bool c1 = q_go_right<MS, false>(q_xread<true, false, CSHIFT>(nullptr, n1, pos), n1);
+            const uint32_t lo = c0 ? nb.z : nb.x, hi = c0 ? nb.w : nb.y;
+            const float v = __uint_as_float(c1 ? hi : lo);
+            if (WRITE_LEAF) {
+                if (t < num_trees && row < rows)
+                    leaf_out[row * (size_t)total_trees + tree_base + t] =
+                        leaf_orig[(size_t)t * ((size_t)n_blocks * 4) + (size_t)bs * 4 + 2 * (c0 ? 1 : 0) + (c1 ? 1 : 0)];
+            }
+            const int t_last = min(g * TPW + TPW - 1, num_trees - 1);
+            if (t_last >= RE) {  // the group's ring entries still in use?
+                int spins = 0;
+                while (lds_flag_load(consumed) < (uint32_t)(t_last - RE + 1)) {
+                    if (++spins > kQSpinLimit) {
+                        dead = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            if (t < num_trees) ring_vals[(t % RE) * RT + r] = v;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // values before the flags (in-order LDS)
+            if (r == 0 && t < num_trees) lds_flag_store(&ring_ready[t % RE], (uint32_t)(t + 1));
+        };
+        int g_p = -1;  // group whose bottom blocks are in flight
+        uint4 na_p = {}, nb_p = {};
+        uint32_t bsel_p = 0;
+        for (int g = wave; g < n_groups && !dead; g += NWALK) {
+            const bool more = g + NWALK < n_groups;
+            if (more) prefetch_tops(g + NWALK);
+            const int t = min(g * TPW + j, num_trees - 1);  // lanes of a missing tree repeat the last one, unused
+            uint32_t i = 1;
+            if (lw > 0) {
+                uint32_t node = slot[1];
+                for (int l = 0; l < lw - 1; ++l) {
+                    const uint32_t xc = q_xread<true, false, CSHIFT>(nullptr, node, pos);
+                    const uint2 pr = *reinterpret_cast<const uint2 *>(&slot[2 * i]);  // children 2i, 2i+1
+                    const uint64_t cm = q_right_mask<MS, false>(xc, node);
+                    i = q_descend(i, cm);
+                    node = __builtin_amdgcn_inverse_ballot_w64(cm) ? pr.y : pr.x;
+                }
+                const uint32_t xc = q_xread<true, false, CSHIFT>(nullptr, node, pos);
+                i = q_descend(i, q_right_mask<MS, false>(xc, node));
+            }
+            uint32_t idx = i - 1;  // 0-based heap index on level lw
+            if (lw < depth - 2) {  // the levels between the slot and the bottom blocks: quantised heap in global memory
+                const uint32_t *tree = qinner + (size_t)t * n_inner;
+                for (int l = lw; l < depth - 2; ++l) {
+                    const uint32_t n = tree[idx];
+                    const uint32_t xc = q_xread<true, false, CSHIFT>(nullptr, n, pos);
+                    idx = 2u * idx + 1u + (q_go_right<MS, false>(xc, n) ? 1u : 0u);
+                }
+            }
+            const uint32_t bsel = idx - first_block_node;
+            if (g_p >= 0) finish(g_p, na_p, nb_p, bsel_p);
+            g_p = g;
+            const uint4 *bp = blocks + ((size_t)t * n_blocks + bsel) * 2;
+            na_p = bp[0];
+            nb_p = bp[1];
+            bsel_p = bsel;
+            if (more) commit_tops();
+        }
+        if (g_p >= 0 && !dead) finish(g_p, na_p, nb_p, bsel_p);
+    };
+    if (chunk_flags[row0 / kQuantRowsPerBlock] != 0)
+        run(std::true_type{});
+    else
+        run(std::false_type{});
+    if (dead && lane == 0) atomicOr(error_flag, 1);
+}
+
+// ------------------------------------------------------------------------------------------------
 static long long qring_lds_for(const tahoe_forest *f, int nwalk, bool lds_tile = true)
 {
     return (lds_tile ? (long long)f->p.num_cols * kQRows * 2 : 0) + (long long)nwalk * kQSlotBytes +
@@ -677,6 +877,35 @@ static long long qring_lds_for(const tahoe_forest *f, int nwalk, bool lds_tile =
 constexpr int kGxWalkers = 15;  // walkers of the GX form (no LDS tile)
 // true: the 128-row u16 tile fits LDS beside at least 4 walkers; false: GX form
 bool qring_lds_tile(const tahoe_forest *f) { return qring_lds_for(f, 4) <= f->lds_limit; }
+
+// Wide form, `rt` rows per tile: a wave's slot holds TPW = 64 / rt tops of 2^lw u32, at most 4 KiB
+static int qwide_lw_max(int top_levels, int rt) { return std::min(top_levels, rt == 64 ? 10 : rt == 32 ? 9 : 8); }
+static long long qwide_slot_bytes(int lw, int rt) { return (64 / rt) * (long long)std::max(1, (1 << lw) >> 2) * 16; }
+static long long qwide_lds_for(const tahoe_forest *f, int rt, int lw)
+{
+    return (long long)f->p.num_cols * rt * 2 + 15LL * qwide_slot_bytes(lw, rt) + kWideRingBytes +
+           (kWideRingBytes / (rt * 4) + 1) * 4LL;
+}
+// rows per tile of the wide-row form (qwide_kernel); 0 = not used (the 128-row tile fits, or not even 16 rows do)
+int qwide_rows(const tahoe_forest *f) { return f->q ? f->q->wide_rt : 0; }
+// Largest tile first; within a tile size up to three top levels may move from the LDS slots to the global heap to
+// make room for the tile.
+static void qwide_pick(const tahoe_forest *f, int *rt_out, int *lw_out)
+{
+    *rt_out = *lw_out = 0;
+    if (!f->q || qring_lds_tile(f)) return;
+    if (const char *e = getenv("TAHOE_QRING_WIDE"))  // experiments: 0 keeps the GX form
+        if (atoi(e) == 0) return;
+    for (int rt : {64, 32, 16}) {
+        const int hi = qwide_lw_max(f->q->top_levels, rt);
+        for (int lw = hi; lw >= std::max(0, hi - 3); --lw)
+            if (qwide_lds_for(f, rt, lw) <= f->lds_limit) {
+                *rt_out = rt;
+                *lw_out = lw;
+                return;
+            }
+    }
+}
 
 int qring_walkers(const tahoe_forest *f)
 {
@@ -985,6 +1214,8 @@ tahoe_status qring_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner,
     f->q = q;
     q->top_levels = f->top_levels;
     q->have_mid = f->depth - 2 > q->top_levels;
+    qwide_pick(f, &q->wide_rt, &q->wide_lw);
+    if (q->wide_rt) q->have_mid = q->have_mid || f->depth - 2 > q->wide_lw;  // smaller tops in LDS
     q->top_stride = (int)std::max<size_t>((size_t)1 << q->top_levels, 4);  // >= 16 bytes per tree
     {
         const char *e = getenv("TAHOE_QRING_NARROW");  // experiments: 0 keeps the general node layout
@@ -1024,6 +1255,9 @@ tahoe_status qring_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner,
         return bad("attr(gx)");
     if ((e = allow_max_lds(reinterpret_cast<const void *>(&qring_kernel<kGxWalkers, true, false>), f->lds_limit)) != hipSuccess)
         return bad("attr(gx)");
+    for (const void *k : {(const void *)&qwide_kernel<64, false>, (const void *)&qwide_kernel<64, true>, (const void *)&qwide_kernel<32, false>,
+                          (const void *)&qwide_kernel<32, true>, (const void *)&qwide_kernel<16, false>, (const void *)&qwide_kernel<16, true>})
+        if ((e = allow_max_lds(k, f->lds_limit)) != hipSuccess) return bad("attr(qwide)");
     if ((e = allow_max_lds(reinterpret_cast<const void *>(&quantize_pair_kernel), f->lds_limit)) != hipSuccess)
         return bad("attr(quantize_pair)");
     if ((e = allow_max_lds(reinterpret_cast<const void *>(&quantize_bucket_pair_kernel), f->lds_limit)) != hipSuccess)
@@ -1088,6 +1322,26 @@ static void q_launch(tahoe_forest *f, const tahoe_qgroup &g, float *sums, const 
                            q->top_levels, q->top_stride, q->chunk_flags, f->error_flag, sums_in, g.tree_lo, f->p.num_trees);
 }
 
+template <int RT>
+static void qwide_launch(tahoe_forest *f, const tahoe_qgroup &g, float *sums, const float *sums_in, uint32_t *leaf_out,
+                         size_t rows, hipStream_t stream)
+{
+    tahoe_qstate *q = f->q;
+    const unsigned grid = (unsigned)((rows + RT - 1) / RT);
+    const int lds = (int)qwide_lds_for(f, RT, q->wide_lw);
+    const uint32_t *leaf_orig = f->leaf_orig + (size_t)g.tree_lo * f->n_leaf;
+    if (leaf_out)
+        hipLaunchKernelGGL((qwide_kernel<RT, true>), dim3(grid), dim3(16 * 64), lds, stream, q->xq, g.top, g.blocks, g.qinner,
+                           leaf_orig, sums, leaf_out, rows, f->p.num_cols, g.num_trees, f->depth, q->top_levels, q->top_stride,
+                           q->chunk_flags, f->error_flag, sums_in, g.tree_lo, f->p.num_trees,
+                           (int)qwide_slot_bytes(q->wide_lw, RT), q->wide_lw);
+    else
+        hipLaunchKernelGGL((qwide_kernel<RT, false>), dim3(grid), dim3(16 * 64), lds, stream, q->xq, g.top, g.blocks, g.qinner,
+                           leaf_orig, sums, leaf_out, rows, f->p.num_cols, g.num_trees, f->depth, q->top_levels, q->top_stride,
+                           q->chunk_flags, f->error_flag, sums_in, g.tree_lo, f->p.num_trees,
+                           (int)qwide_slot_bytes(q->wide_lw, RT), q->wide_lw);
+}
+
 tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, const float *data, size_t rows,
                           hipStream_t stream, hipEvent_t mid_event)
 {
@@ -1100,6 +1354,10 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
     tahoe_status s = qring_reserve(f, rows);  // no-op unless this batch is larger than any before
     if (s != TAHOE_OK) return s;
     const size_t chunks = (rows + kQuantRowsPerBlock - 1) / kQuantRowsPerBlock;
+    const int wide = qwide_rows(f);  // 0: 128-row tiles; else rows per tile of the wide-row form
+    const int trs = wide == 64 ? 6 : wide == 32 ? 5 : wide == 16 ? 4 : 7;
+    if ((rows + (wide ? wide : kQRows) - 1) / (wide ? wide : kQRows) > 0x7fffffffu)
+        return fail(TAHOE_ERR_INVALID_ARG, "too many rows for one launch");
     bool first = true;
     for (const tahoe_qgroup &g : q->groups) {  // stream order: quantise for the group, walk the group, next group
         TAHOE_HIP_TRY(hipMemsetAsync(q->chunk_flags, 0, q->n_chunk_flags * sizeof(uint32_t), stream));
@@ -1109,19 +1367,25 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
         if (pair_ok && g.buckets > 0)
             hipLaunchKernelGGL(quantize_bucket_pair_kernel, dim3((unsigned)qgrid), dim3(kQuantPairThreads),
                                (size_t)g.bucket_lds_bytes, stream, data, g.bsorted, g.boffsets, g.bstarts, g.bparams, q->xq,
-                               q->chunk_flags, rows, f->p.num_cols, f->p.missing, g.buckets);
+                               q->chunk_flags, rows, f->p.num_cols, f->p.missing, g.buckets, trs);
         else if (pair_ok)
             hipLaunchKernelGGL(quantize_pair_kernel, dim3((unsigned)qgrid), dim3(kQuantPairThreads),
                                (size_t)g.pair_lds_floats * 4, stream, data, g.tables, g.offsets, q->xq, q->chunk_flags, rows,
-                               f->p.num_cols, f->p.missing, g.pair_lds_floats);
+                               f->p.num_cols, f->p.missing, g.pair_lds_floats, trs);
         else
             hipLaunchKernelGGL(quantize_kernel<1>, dim3((unsigned)qgrid), dim3(kQuantThreads), (size_t)std::max(g.max_table, 1) * 4,
                                stream, data, g.tables, g.offsets, q->xq, q->chunk_flags, rows, f->p.num_cols, f->p.missing,
-                               std::max(g.max_table, 1));
+                               std::max(g.max_table, 1), trs);
         TAHOE_HIP_TRY(hipGetLastError());
         if (first && mid_event) TAHOE_HIP_TRY(hipEventRecord(mid_event, stream));  // splits pre-pass / walk for 1 group
         const float *sums_in = first ? nullptr : sums;  // later groups continue the running float32 sums
-        if (!qring_lds_tile(f))
+        if (wide == 64)
+            qwide_launch<64>(f, g, sums, sums_in, leaf_out, rows, stream);
+        else if (wide == 32)
+            qwide_launch<32>(f, g, sums, sums_in, leaf_out, rows, stream);
+        else if (wide == 16)
+            qwide_launch<16>(f, g, sums, sums_in, leaf_out, rows, stream);
+        else if (!qring_lds_tile(f))
             q_launch<kGxWalkers, false>(f, g, sums, sums_in, leaf_out, rows, stream);
         else
         switch (nwalk) {

@@ -479,3 +479,31 @@ def test_fuzz_shapes_against_the_oracle(env):
             assert np.array_equal(bits(sums.cpu().numpy()), bits(want)), case
             assert np.array_equal(bits(leaf.cpu().numpy()), sl), case
             f.close()
+
+
+WIDE_SHAPES = [
+    # T, D, C, R, leaf_prob: rows too wide for a 128-row u16 tile -> 64 / 32 / 16-row tiles, several trees per wave
+    (6, 7, 3072, 200, 0.0),     # K2 width: 16-row tiles, 4 trees per wave
+    (7, 12, 1200, 300, 0.0),    # 32-row tiles; the LDS slot holds 9 of the 10 top levels, level 10 from the heap
+    (5, 13, 3072, 77, 0.1),     # 16-row tiles; levels 9..11 from the quantised heap in global memory
+    (9, 3, 700, 130, 0.0),      # 64-row tiles, one tree per wave
+    (3, 0, 2000, 50, 0.0),      # depth 0 -> De = 2: no top levels at all
+    (130, 6, 1024, 1000, 0.2),  # more trees than two ring rounds
+    (1, 2, 5000, 33, 0.0),      # not even 16 rows fit: features from the quantised tile in L2 (GX form)
+    (67, 9, 2048, 4097, 0.05),  # tree count not a multiple of the trees per wave, rows not of the tile
+]
+
+
+@pytest.mark.parametrize("T,D,C,R,leaf_prob", WIDE_SHAPES)
+def test_wide_rows(env, T, D, C, R, leaf_prob):
+    ta = env[0]
+    nodes = ta.synth_forest(T, D, C, seed=300 + T, leaf_prob=leaf_prob)
+    data = ta.synth_data(R, C, seed=400 + R, missing_prob=0.05, missing=MISSING, nan_prob=0.02)
+    f = ta.Forest(nodes, T, D, C, missing=MISSING)
+    want_rows = {3072: 16, 1200: 32, 700: 64, 2000: 32, 1024: 64, 5000: 0, 2048: 32}[C]
+    assert f.info().qring_tile_rows == want_rows, (C, f.info().qring_tile_rows)
+    f.close()
+    run_case(env, nodes, T, D, C, data, strategies=[ta.STRATEGY_QRING, ta.STRATEGY_DIRECT, ta.STRATEGY_AUTO])
+    # no missing values at all: the single-compare fast path
+    clean = ta.synth_data(R, C, seed=500 + R)
+    run_case(env, nodes, T, D, C, clean, strategies=[ta.STRATEGY_QRING])
