@@ -44,6 +44,7 @@ struct tahoe_qgroup {
     int tree_lo = 0, num_trees = 0;
     int max_table = 0;            // floats of the largest per-feature search tree (2^p)
     int pair_lds_floats = 0;      // LDS floats of quantize_pair_kernel; 0 = odd num_cols, single-feature form
+    int multi_q = 0;              // quantize_multi_kernel<Q>: 4 or 2 (16 / 8 features per workgroup); 0 = tables too large
     float *tables = nullptr;      // concatenated search trees
     int *offsets = nullptr;       // [cols + 1]
     // bucketed form (quantize_bucket_pair_kernel): sorted thresholds + a direct-index table per feature
@@ -372,6 +373,76 @@ __global__ void __launch_bounds__(kQuantPairThreads)
                 saw_missing |= ms0 | ms1;
                 dst[0] = (uint16_t)(ms0 ? kCodeMissing : (uint32_t)c0[u]);
                 dst[(size_t)1 << trs] = (uint16_t)(ms1 ? kCodeMissing : (uint32_t)c1[u]);
+            }
+        }
+    }
+    if (__ballot(saw_missing) != 0 && (threadIdx.x & 63) == 0) atomicOr(&chunk_flags[chunk], 1u);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Many features per workgroup, for forests whose per-feature tables are small (K2: 3072 features x ~40 thresholds).
+// The pair kernels read 8 bytes of every 64-byte line they touch and are bound by the texture path (one cache
+// line per lane); with F = 4 * Q features per workgroup a row is read by Q adjacent lanes as float4, F = 16 uses
+// whole lines.  Tables: the Eytzinger search trees (a few hundred bytes each), descent as in quantize_kernel; the
+// trip count is per lane (adjacent lanes serve different features), a wave runs to its longest.
+template <int Q>
+__global__ void __launch_bounds__(kQuantPairThreads)
+    quantize_multi_kernel(const float *__restrict__ data, const float *__restrict__ tables, const int *__restrict__ offsets,
+                          uint16_t *__restrict__ xq, uint32_t *__restrict__ chunk_flags, size_t rows, int cols, float missing,
+                          int tab_stride, int trs)
+{
+    constexpr int F = 4 * Q;
+    constexpr int RPI = kQuantPairThreads / Q;  // rows per block iteration
+    constexpr int U = 2;                        // rows per thread and iteration: 8 independent descents
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *tab = reinterpret_cast<float *>(smem);
+    const unsigned nblk = gridDim.x;
+    const unsigned vid = (nblk % 8u == 0u) ? (blockIdx.x % 8u) * (nblk / 8u) + blockIdx.x / 8u : blockIdx.x;  // XCD-contiguous
+    const int groups = cols / F;
+    const int f0 = (int)(vid % groups) * F;
+    const size_t chunk = vid / groups;
+    for (int j = 0; j < F; ++j) {
+        const int base = offsets[f0 + j], size = offsets[f0 + j + 1] - base;
+        for (int i = threadIdx.x; i < size; i += blockDim.x) tab[j * tab_stride + i] = tables[base + i];
+    }
+    const int quad = threadIdx.x % Q, rsub = threadIdx.x / Q;
+    const int fq = f0 + 4 * quad;  // this thread's four features
+    int size[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) size[j] = offsets[fq + j + 1] - offsets[fq + j];
+    __syncthreads();
+    const size_t r0 = chunk * kQuantRowsPerBlock;
+    const size_t r1 = min(rows, r0 + (size_t)kQuantRowsPerBlock);
+    bool saw_missing = false;
+    for (size_t rb = r0 + rsub; rb < r1; rb += (size_t)RPI * U) {
+        float4 xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t r = min(rb + (size_t)u * RPI, r1 - 1);  // clamped: in bounds, result unused
+            xv[u] = *reinterpret_cast<const float4 *>(data + r * (size_t)cols + fq);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float *tj = tab + (4 * quad + j) * tab_stride;
+            float x[U];
+            int cnt[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                x[u] = qv_get(xv[u], j);
+                cnt[u] = 1;
+            }
+            for (int lim = size[j]; lim > 1; lim >>= 1) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) cnt[u] = 2 * cnt[u] + (tj[cnt[u]] <= x[u] ? 1 : 0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const size_t r = rb + (size_t)u * RPI;
+                if (r < r1) {
+                    const bool ms = fabsf(x[u] - missing) <= kMissingEps;
+                    saw_missing |= ms;
+                    xq[q_tile_index(r, fq + j, cols, trs)] = (uint16_t)(ms ? kCodeMissing : (uint32_t)(cnt[u] - size[j]));
+                }
             }
         }
     }
@@ -1180,6 +1251,16 @@ static tahoe_status build_group(tahoe_forest *f, const std::vector<InnerNode> &h
         }
         g.pair_lds_floats = std::max(need, 1);
     }
+    g.multi_q = 0;
+    {
+        const char *e = getenv("TAHOE_QUANT_MULTI");  // experiments: 0 keeps the pair kernels
+        if (!(e && atoi(e) == 0))
+            for (int qd : {4, 2})
+                if (cols % (4 * qd) == 0 && (long long)4 * qd * max_size * 4 <= f->lds_limit - 256) {
+                    g.multi_q = qd;
+                    break;
+                }
+    }
     {
         const tahoe_status bs = build_buckets(f, tab, g);
         if (bs != TAHOE_OK) return bs;
@@ -1260,6 +1341,10 @@ tahoe_status qring_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner,
         if ((e = allow_max_lds(k, f->lds_limit)) != hipSuccess) return bad("attr(qwide)");
     if ((e = allow_max_lds(reinterpret_cast<const void *>(&quantize_pair_kernel), f->lds_limit)) != hipSuccess)
         return bad("attr(quantize_pair)");
+    if ((e = allow_max_lds(reinterpret_cast<const void *>(&quantize_multi_kernel<4>), f->lds_limit)) != hipSuccess)
+        return bad("attr(quantize_multi)");
+    if ((e = allow_max_lds(reinterpret_cast<const void *>(&quantize_multi_kernel<2>), f->lds_limit)) != hipSuccess)
+        return bad("attr(quantize_multi)");
     if ((e = allow_max_lds(reinterpret_cast<const void *>(&quantize_bucket_pair_kernel), f->lds_limit)) != hipSuccess)
         return bad("attr(quantize_bucket_pair)");
     if ((e = allow_max_lds(reinterpret_cast<const void *>(&quantize_kernel<1>), f->lds_limit)) != hipSuccess)
@@ -1362,9 +1447,18 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
     for (const tahoe_qgroup &g : q->groups) {  // stream order: quantise for the group, walk the group, next group
         TAHOE_HIP_TRY(hipMemsetAsync(q->chunk_flags, 0, q->n_chunk_flags * sizeof(uint32_t), stream));
         const bool pair_ok = g.pair_lds_floats > 0 && (reinterpret_cast<uintptr_t>(data) % 8) == 0;  // float2 loads
-        const size_t qgrid = chunks * (size_t)(pair_ok ? f->p.num_cols / 2 : f->p.num_cols);
+        const bool multi_ok = g.multi_q > 0 && (reinterpret_cast<uintptr_t>(data) % 16) == 0;  // float4 loads
+        const size_t qgrid = chunks * (size_t)(multi_ok ? f->p.num_cols / (4 * g.multi_q) : pair_ok ? f->p.num_cols / 2 : f->p.num_cols);
         if (qgrid > 0x7fffffffu) return fail(TAHOE_ERR_INVALID_ARG, "too many rows x cols for one launch");
-        if (pair_ok && g.buckets > 0)
+        if (multi_ok && g.multi_q == 4)
+            hipLaunchKernelGGL(quantize_multi_kernel<4>, dim3((unsigned)qgrid), dim3(kQuantPairThreads),
+                               (size_t)16 * std::max(g.max_table, 1) * 4, stream, data, g.tables, g.offsets, q->xq, q->chunk_flags,
+                               rows, f->p.num_cols, f->p.missing, std::max(g.max_table, 1), trs);
+        else if (multi_ok)
+            hipLaunchKernelGGL(quantize_multi_kernel<2>, dim3((unsigned)qgrid), dim3(kQuantPairThreads),
+                               (size_t)8 * std::max(g.max_table, 1) * 4, stream, data, g.tables, g.offsets, q->xq, q->chunk_flags,
+                               rows, f->p.num_cols, f->p.missing, std::max(g.max_table, 1), trs);
+        else if (pair_ok && g.buckets > 0)
             hipLaunchKernelGGL(quantize_bucket_pair_kernel, dim3((unsigned)qgrid), dim3(kQuantPairThreads),
                                (size_t)g.bucket_lds_bytes, stream, data, g.bsorted, g.boffsets, g.bstarts, g.bparams, q->xq,
                                q->chunk_flags, rows, f->p.num_cols, f->p.missing, g.buckets, trs);

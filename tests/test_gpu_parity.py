@@ -387,15 +387,16 @@ def test_host_batches_through_the_upload_pipeline(env, pinned):
         pin.close()
 
 
-@pytest.mark.parametrize("buckets", ["1", "0"])
-def test_quantiser_on_skewed_thresholds(env, monkeypatch, buckets):
+@pytest.mark.parametrize("form", ["buckets", "tree", "multi"])
+def test_quantiser_on_skewed_thresholds(env, monkeypatch, form):
     """The bucketed quantiser maps x to a run of the sorted thresholds with a monotone linear map; a skewed
     distribution (almost everything in a sliver of the range, a few huge outliers, one constant feature, one
     feature with only infinite thresholds) makes some runs long but may not change a single code.  Feature values
-    sit on thresholds, one ulp either side of them, and far outside.  Both quantiser forms (TAHOE_QUANT_BUCKETS)
-    against the oracle."""
+    sit on thresholds, one ulp either side of them, and far outside.  All quantiser forms against the oracle."""
     ta, oracle, torch = env
-    monkeypatch.setenv("TAHOE_QUANT_BUCKETS", buckets)
+    # the three quantise kernels: bucketed pair form, search-tree pair form, many-features-per-workgroup form
+    monkeypatch.setenv("TAHOE_QUANT_MULTI", "1" if form == "multi" else "0")
+    monkeypatch.setenv("TAHOE_QUANT_BUCKETS", "0" if form == "tree" else "1")
     rng = np.random.default_rng(11)
     T, D, C, R = 60, 9, 8, 6000
     nodes = ta.synth_forest(T, D, C, seed=81)
