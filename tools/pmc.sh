@@ -19,6 +19,6 @@ for n in "abcde":
     for f in glob.glob("$R/gpurun_out/pmc_${tag}_%s/*/*_counter_collection.csv"%n):
         acc=collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if "tahoe" in r["Kernel_Name"]: acc[(r["Kernel_Name"].split("(")[0][-40:],r["Counter_Name"])].append(float(r["Counter_Value"]))
+            if "tahoe" in r["Kernel_Name"]: acc[(r["Kernel_Name"].split("(")[0][-60:],r["Counter_Name"])].append(float(r["Counter_Value"]))
         for k,v in sorted(acc.items()): print(k[0],k[1],"%.5g"%(sum(v)/len(v)))
 PY
