@@ -704,7 +704,15 @@ static int resolve_strategy(const tahoe_forest *f, size_t /*rows*/)
         return sparse_tile_fits(f) ? TAHOE_STRATEGY_ROWTILE : TAHOE_STRATEGY_DIRECT;
     }
     if (f->strategy != TAHOE_STRATEGY_AUTO) return f->strategy;
-    if (qring_walkers(f) > 0) return TAHOE_STRATEGY_QRING;
+    // QRING pays a quantise pass over rows x cols to make every (row, tree, level) step ~3x cheaper.  Fitted on the
+    // enumeration of tools/selector_check.py (profiles/r01/selector_vs_enumeration.json): it loses to ROWTILE on
+    // very shallow trees (the whole tree sits in ROWTILE's LDS top, no pre-pass) and to the float32 tile kernels
+    // when there is little walking per feature value (trees x depth < 4 x cols).
+    const bool shallow = f->depth <= 4 && rowtile_fits(f);
+    const bool little_work = (long long)f->p.num_trees * f->depth < 4LL * f->p.num_cols &&
+                             (tilering_rows(f) > 0 || tileblock_rows(f) > 0 || rowtile_fits(f));
+    if (shallow) return TAHOE_STRATEGY_ROWTILE;
+    if (qring_walkers(f) > 0 && !little_work) return TAHOE_STRATEGY_QRING;
     if (tilering_rows(f) > 0) return TAHOE_STRATEGY_TILERING;
     if (tileblock_rows(f) > 0) return TAHOE_STRATEGY_TILEBLOCK;
     return rowtile_fits(f) ? TAHOE_STRATEGY_ROWTILE : TAHOE_STRATEGY_DIRECT;

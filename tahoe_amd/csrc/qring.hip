@@ -81,7 +81,8 @@ constexpr int kQBatch = 8;                  // trees the consumer takes per poll
 constexpr int kQSpinLimit = 1 << 22;
 constexpr int kQSlotBytes = 4096;            // LDS per walker: a 10-level top (2^10 u32)
 constexpr int kQMaxTable = 32767;
-constexpr int kQuantRowsPerBlock = 32768;   // rows one quantise workgroup converts for its feature
+constexpr int kQuantMaxShift = 15;          // a quantise workgroup converts 2^cshift rows of its features; at most 32768
+constexpr int kQuantMinRowsPerBlock = 512;  // ... and the fewest
 constexpr int kQuantThreads = 512;
 constexpr uint32_t kCodeMissing = 0xFFFFu;
 
@@ -118,7 +119,7 @@ template <int F>
 __global__ void __launch_bounds__(kQuantThreads) quantize_kernel(const float *__restrict__ data, const float *__restrict__ tables,
                                                                  const int *__restrict__ offsets, uint16_t *__restrict__ xq,
                                                                  uint32_t *__restrict__ chunk_flags, size_t rows, int cols,
-                                                                 float missing, int tab_stride, int trs)
+                                                                 float missing, int tab_stride, int trs, int cshift)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *tab = reinterpret_cast<float *>(smem);
@@ -142,8 +143,8 @@ __global__ void __launch_bounds__(kQuantThreads) quantize_kernel(const float *__
         for (int i = threadIdx.x; i < size[j]; i += blockDim.x) tab[j * tab_stride + i] = tables[base + i];
     }
     __syncthreads();
-    const size_t r0 = chunk * kQuantRowsPerBlock;
-    const size_t r1 = min(rows, r0 + (size_t)kQuantRowsPerBlock);
+    const size_t r0 = chunk << cshift;
+    const size_t r1 = min(rows, r0 + ((size_t)1 << cshift));
     constexpr int U = (F == 1) ? 4 : 2;  // rows per thread and iteration: U * F independent search chains
     using V = typename QVec<F>::T;
     bool saw_missing = false;
@@ -194,7 +195,7 @@ constexpr int kQuantPairThreads = 1024;
 __global__ void __launch_bounds__(kQuantPairThreads)
     quantize_pair_kernel(const float *__restrict__ data, const float *__restrict__ tables, const int *__restrict__ offsets,
                          uint16_t *__restrict__ xq, uint32_t *__restrict__ chunk_flags, size_t rows, int cols, float missing,
-                         int lds_floats, int trs)
+                         int lds_floats, int trs, int cshift)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *tab = reinterpret_cast<float *>(smem);
@@ -206,8 +207,8 @@ __global__ void __launch_bounds__(kQuantPairThreads)
     const int base0 = offsets[f0], base1 = offsets[f0 + 1];
     const int size0 = base1 - base0, size1 = offsets[f0 + 2] - base1;
     const bool together = size0 + size1 <= lds_floats;
-    const size_t r0 = chunk * kQuantRowsPerBlock;
-    const size_t r1 = min(rows, r0 + (size_t)kQuantRowsPerBlock);
+    const size_t r0 = chunk << cshift;
+    const size_t r1 = min(rows, r0 + ((size_t)1 << cshift));
     constexpr int U = 4;  // rows per thread and iteration: 8 independent search chains hide the LDS latency
     bool saw_missing = false;
     for (int pass = 0; pass < (together ? 1 : 2); ++pass) {
@@ -294,7 +295,7 @@ __global__ void __launch_bounds__(kQuantPairThreads)
     quantize_bucket_pair_kernel(const float *__restrict__ data, const float *__restrict__ bsorted, const int *__restrict__ boffsets,
                                 const uint16_t *__restrict__ bstarts, const float4 *__restrict__ bparams,
                                 uint16_t *__restrict__ xq, uint32_t *__restrict__ chunk_flags, size_t rows, int cols, float missing,
-                                int B, int trs)
+                                int B, int trs, int cshift)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned nblk = gridDim.x;
@@ -319,8 +320,8 @@ __global__ void __launch_bounds__(kQuantPairThreads)
     const int steps0 = __float_as_int(p0.z), steps1 = __float_as_int(p1.z);
     const float bm1 = (float)(B - 1);
     __syncthreads();
-    const size_t r0 = chunk * kQuantRowsPerBlock;
-    const size_t r1 = min(rows, r0 + (size_t)kQuantRowsPerBlock);
+    const size_t r0 = chunk << cshift;
+    const size_t r1 = min(rows, r0 + ((size_t)1 << cshift));
     constexpr int U = 4;
     bool saw_missing = false;
     for (size_t rb = r0 + threadIdx.x; rb < r1; rb += (size_t)blockDim.x * U) {
@@ -389,7 +390,7 @@ template <int Q>
 __global__ void __launch_bounds__(kQuantPairThreads)
     quantize_multi_kernel(const float *__restrict__ data, const float *__restrict__ tables, const int *__restrict__ offsets,
                           uint16_t *__restrict__ xq, uint32_t *__restrict__ chunk_flags, size_t rows, int cols, float missing,
-                          int tab_stride, int trs)
+                          int tab_stride, int trs, int cshift)
 {
     constexpr int F = 4 * Q;
     constexpr int RPI = kQuantPairThreads / Q;  // rows per block iteration
@@ -411,8 +412,8 @@ __global__ void __launch_bounds__(kQuantPairThreads)
 #pragma unroll
     for (int j = 0; j < 4; ++j) size[j] = offsets[fq + j + 1] - offsets[fq + j];
     __syncthreads();
-    const size_t r0 = chunk * kQuantRowsPerBlock;
-    const size_t r1 = min(rows, r0 + (size_t)kQuantRowsPerBlock);
+    const size_t r0 = chunk << cshift;
+    const size_t r1 = min(rows, r0 + ((size_t)1 << cshift));
     bool saw_missing = false;
     for (size_t rb = r0 + rsub; rb < r1; rb += (size_t)RPI * U) {
         float4 xv[U];
@@ -526,7 +527,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                  const uint32_t *__restrict__ qinner, const uint32_t *__restrict__ leaf_orig, float *__restrict__ sums,
                  uint32_t *__restrict__ leaf_out, size_t rows, int cols, int num_trees, int depth, int top_levels,
                  int top_stride, const uint32_t *__restrict__ chunk_flags, int *__restrict__ error_flag,
-                 const float *__restrict__ sums_in, int tree_base, int total_trees)
+                 const float *__restrict__ sums_in, int tree_base, int total_trees, int cshift)
 {
     constexpr int K = kQRows / 64;  // two 64-row chains per walker lane
     constexpr int NT = (NWALK + 1) * 64;
@@ -740,8 +741,8 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
         }
         if (t_p >= 0 && !dead) finish(t_p, na_p, nb_p, bsel_p);
     };
-    // chunk_flags[c] != 0 <=> the quantise pass met a missing value in rows [c, c+1) * kQuantRowsPerBlock
-    if (chunk_flags[row0 / kQuantRowsPerBlock] != 0)
+    // chunk_flags[c] != 0 <=> the quantise pass met a missing value in rows [c, c+1) << cshift
+    if (chunk_flags[row0 >> cshift] != 0)
         run(std::true_type{});
     else
         run(std::false_type{});
@@ -764,7 +765,7 @@ __global__ void __launch_bounds__(16 * 64)
                  const uint32_t *__restrict__ qinner, const uint32_t *__restrict__ leaf_orig, float *__restrict__ sums,
                  uint32_t *__restrict__ leaf_out, size_t rows, int cols, int num_trees, int depth, int top_levels,
                  int top_stride, const uint32_t *__restrict__ chunk_flags, int *__restrict__ error_flag,
-                 const float *__restrict__ sums_in, int tree_base, int total_trees, int slot_bytes, int lw)
+                 const float *__restrict__ sums_in, int tree_base, int total_trees, int slot_bytes, int lw, int cshift)
 {
     constexpr int NWALK = 15;
     constexpr int NT = (NWALK + 1) * 64;
@@ -931,7 +932,7 @@ __global__ void __launch_bounds__(16 * 64)
         }
         if (g_p >= 0 && !dead) finish(g_p, na_p, nb_p, bsel_p);
     };
-    if (chunk_flags[row0 / kQuantRowsPerBlock] != 0)
+    if (chunk_flags[row0 >> cshift] != 0)
         run(std::true_type{});
     else
         run(std::false_type{});
@@ -1384,14 +1385,14 @@ tahoe_status qring_reserve(tahoe_forest *f, size_t rows)
     q->xq_rows = tiles * kQRows;
     f->device_bytes += bytes;
     if (q->chunk_flags) TAHOE_HIP_TRY(hipFree(q->chunk_flags));
-    q->n_chunk_flags = (q->xq_rows + kQuantRowsPerBlock - 1) / kQuantRowsPerBlock + 1;
+    q->n_chunk_flags = (q->xq_rows + kQuantMinRowsPerBlock - 1) / kQuantMinRowsPerBlock + 1;
     TAHOE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&q->chunk_flags), q->n_chunk_flags * sizeof(uint32_t)));
     return TAHOE_OK;
 }
 
 template <int NWALK, bool LDSX = true, bool NARROW = false>
 static void q_launch(tahoe_forest *f, const tahoe_qgroup &g, float *sums, const float *sums_in, uint32_t *leaf_out,
-                     size_t rows, hipStream_t stream)
+                     size_t rows, hipStream_t stream, int cshift)
 {
     tahoe_qstate *q = f->q;
     const unsigned grid = (unsigned)((rows + kQRows - 1) / kQRows);
@@ -1400,16 +1401,16 @@ static void q_launch(tahoe_forest *f, const tahoe_qgroup &g, float *sums, const 
     if (leaf_out)
         hipLaunchKernelGGL((qring_kernel<NWALK, true, LDSX, NARROW>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, g.top,
                            g.blocks, g.qinner, leaf_orig, sums, leaf_out, rows, f->p.num_cols, g.num_trees, f->depth,
-                           q->top_levels, q->top_stride, q->chunk_flags, f->error_flag, sums_in, g.tree_lo, f->p.num_trees);
+                           q->top_levels, q->top_stride, q->chunk_flags, f->error_flag, sums_in, g.tree_lo, f->p.num_trees, cshift);
     else
         hipLaunchKernelGGL((qring_kernel<NWALK, false, LDSX, NARROW>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, g.top,
                            g.blocks, g.qinner, leaf_orig, sums, leaf_out, rows, f->p.num_cols, g.num_trees, f->depth,
-                           q->top_levels, q->top_stride, q->chunk_flags, f->error_flag, sums_in, g.tree_lo, f->p.num_trees);
+                           q->top_levels, q->top_stride, q->chunk_flags, f->error_flag, sums_in, g.tree_lo, f->p.num_trees, cshift);
 }
 
 template <int RT>
 static void qwide_launch(tahoe_forest *f, const tahoe_qgroup &g, float *sums, const float *sums_in, uint32_t *leaf_out,
-                         size_t rows, hipStream_t stream)
+                         size_t rows, hipStream_t stream, int cshift)
 {
     tahoe_qstate *q = f->q;
     const unsigned grid = (unsigned)((rows + RT - 1) / RT);
@@ -1419,12 +1420,12 @@ static void qwide_launch(tahoe_forest *f, const tahoe_qgroup &g, float *sums, co
         hipLaunchKernelGGL((qwide_kernel<RT, true>), dim3(grid), dim3(16 * 64), lds, stream, q->xq, g.top, g.blocks, g.qinner,
                            leaf_orig, sums, leaf_out, rows, f->p.num_cols, g.num_trees, f->depth, q->top_levels, q->top_stride,
                            q->chunk_flags, f->error_flag, sums_in, g.tree_lo, f->p.num_trees,
-                           (int)qwide_slot_bytes(q->wide_lw, RT), q->wide_lw);
+                           (int)qwide_slot_bytes(q->wide_lw, RT), q->wide_lw, cshift);
     else
         hipLaunchKernelGGL((qwide_kernel<RT, false>), dim3(grid), dim3(16 * 64), lds, stream, q->xq, g.top, g.blocks, g.qinner,
                            leaf_orig, sums, leaf_out, rows, f->p.num_cols, g.num_trees, f->depth, q->top_levels, q->top_stride,
                            q->chunk_flags, f->error_flag, sums_in, g.tree_lo, f->p.num_trees,
-                           (int)qwide_slot_bytes(q->wide_lw, RT), q->wide_lw);
+                           (int)qwide_slot_bytes(q->wide_lw, RT), q->wide_lw, cshift);
 }
 
 tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, const float *data, size_t rows,
@@ -1438,7 +1439,6 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
                     "u16 tile in LDS", kQMaxTable);
     tahoe_status s = qring_reserve(f, rows);  // no-op unless this batch is larger than any before
     if (s != TAHOE_OK) return s;
-    const size_t chunks = (rows + kQuantRowsPerBlock - 1) / kQuantRowsPerBlock;
     const int wide = qwide_rows(f);  // 0: 128-row tiles; else rows per tile of the wide-row form
     const int trs = wide == 64 ? 6 : wide == 32 ? 5 : wide == 16 ? 4 : 7;
     if ((rows + (wide ? wide : kQRows) - 1) / (wide ? wide : kQRows) > 0x7fffffffu)
@@ -1448,50 +1448,63 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
         TAHOE_HIP_TRY(hipMemsetAsync(q->chunk_flags, 0, q->n_chunk_flags * sizeof(uint32_t), stream));
         const bool pair_ok = g.pair_lds_floats > 0 && (reinterpret_cast<uintptr_t>(data) % 8) == 0;  // float2 loads
         const bool multi_ok = g.multi_q > 0 && (reinterpret_cast<uintptr_t>(data) % 16) == 0;  // float4 loads
-        const size_t qgrid = chunks * (size_t)(multi_ok ? f->p.num_cols / (4 * g.multi_q) : pair_ok ? f->p.num_cols / 2 : f->p.num_cols);
+        // Rows per quantise workgroup (2^cshift): as many as 32768 so that staging the tables is amortised, fewer when
+        // that would leave the chip short of workgroups (few columns or rows), never so few that the tables outweigh
+        // the rows a workgroup converts.
+        const int feats = multi_ok ? 4 * g.multi_q : pair_ok ? 2 : 1;
+        const size_t fgroups = (size_t)f->p.num_cols / feats;
+        const size_t table_bytes = multi_ok ? (size_t)feats * std::max(g.max_table, 1) * 4
+                                   : (pair_ok && g.buckets > 0) ? (size_t)g.bucket_lds_bytes
+                                   : pair_ok ? (size_t)g.pair_lds_floats * 4 : (size_t)std::max(g.max_table, 1) * 4;
+        int cshift = kQuantMaxShift;
+        while ((1 << cshift) > kQuantMinRowsPerBlock && ((rows + ((size_t)1 << cshift) - 1) >> cshift) * fgroups < (size_t)8 * f->num_cus &&
+               ((size_t)1 << (cshift - 1)) * feats * 4 >= 2 * table_bytes)
+            --cshift;
+        const size_t chunks = (rows + ((size_t)1 << cshift) - 1) >> cshift;
+        const size_t qgrid = chunks * fgroups;
         if (qgrid > 0x7fffffffu) return fail(TAHOE_ERR_INVALID_ARG, "too many rows x cols for one launch");
         if (multi_ok && g.multi_q == 4)
             hipLaunchKernelGGL(quantize_multi_kernel<4>, dim3((unsigned)qgrid), dim3(kQuantPairThreads),
                                (size_t)16 * std::max(g.max_table, 1) * 4, stream, data, g.tables, g.offsets, q->xq, q->chunk_flags,
-                               rows, f->p.num_cols, f->p.missing, std::max(g.max_table, 1), trs);
+                               rows, f->p.num_cols, f->p.missing, std::max(g.max_table, 1), trs, cshift);
         else if (multi_ok)
             hipLaunchKernelGGL(quantize_multi_kernel<2>, dim3((unsigned)qgrid), dim3(kQuantPairThreads),
                                (size_t)8 * std::max(g.max_table, 1) * 4, stream, data, g.tables, g.offsets, q->xq, q->chunk_flags,
-                               rows, f->p.num_cols, f->p.missing, std::max(g.max_table, 1), trs);
+                               rows, f->p.num_cols, f->p.missing, std::max(g.max_table, 1), trs, cshift);
         else if (pair_ok && g.buckets > 0)
             hipLaunchKernelGGL(quantize_bucket_pair_kernel, dim3((unsigned)qgrid), dim3(kQuantPairThreads),
                                (size_t)g.bucket_lds_bytes, stream, data, g.bsorted, g.boffsets, g.bstarts, g.bparams, q->xq,
-                               q->chunk_flags, rows, f->p.num_cols, f->p.missing, g.buckets, trs);
+                               q->chunk_flags, rows, f->p.num_cols, f->p.missing, g.buckets, trs, cshift);
         else if (pair_ok)
             hipLaunchKernelGGL(quantize_pair_kernel, dim3((unsigned)qgrid), dim3(kQuantPairThreads),
                                (size_t)g.pair_lds_floats * 4, stream, data, g.tables, g.offsets, q->xq, q->chunk_flags, rows,
-                               f->p.num_cols, f->p.missing, g.pair_lds_floats, trs);
+                               f->p.num_cols, f->p.missing, g.pair_lds_floats, trs, cshift);
         else
             hipLaunchKernelGGL(quantize_kernel<1>, dim3((unsigned)qgrid), dim3(kQuantThreads), (size_t)std::max(g.max_table, 1) * 4,
                                stream, data, g.tables, g.offsets, q->xq, q->chunk_flags, rows, f->p.num_cols, f->p.missing,
-                               std::max(g.max_table, 1), trs);
+                               std::max(g.max_table, 1), trs, cshift);
         TAHOE_HIP_TRY(hipGetLastError());
         if (first && mid_event) TAHOE_HIP_TRY(hipEventRecord(mid_event, stream));  // splits pre-pass / walk for 1 group
         const float *sums_in = first ? nullptr : sums;  // later groups continue the running float32 sums
         if (wide == 64)
-            qwide_launch<64>(f, g, sums, sums_in, leaf_out, rows, stream);
+            qwide_launch<64>(f, g, sums, sums_in, leaf_out, rows, stream, cshift);
         else if (wide == 32)
-            qwide_launch<32>(f, g, sums, sums_in, leaf_out, rows, stream);
+            qwide_launch<32>(f, g, sums, sums_in, leaf_out, rows, stream, cshift);
         else if (wide == 16)
-            qwide_launch<16>(f, g, sums, sums_in, leaf_out, rows, stream);
+            qwide_launch<16>(f, g, sums, sums_in, leaf_out, rows, stream, cshift);
         else if (!qring_lds_tile(f))
-            q_launch<kGxWalkers, false>(f, g, sums, sums_in, leaf_out, rows, stream);
+            q_launch<kGxWalkers, false>(f, g, sums, sums_in, leaf_out, rows, stream, cshift);
         else
         switch (nwalk) {
             case 15:
                 if (q->narrow)
-                    q_launch<15, true, true>(f, g, sums, sums_in, leaf_out, rows, stream);
+                    q_launch<15, true, true>(f, g, sums, sums_in, leaf_out, rows, stream, cshift);
                 else
-                    q_launch<15>(f, g, sums, sums_in, leaf_out, rows, stream);
+                    q_launch<15>(f, g, sums, sums_in, leaf_out, rows, stream, cshift);
                 break;
-            case 12: q_launch<12>(f, g, sums, sums_in, leaf_out, rows, stream); break;
-            case 8: q_launch<8>(f, g, sums, sums_in, leaf_out, rows, stream); break;
-            default: q_launch<4>(f, g, sums, sums_in, leaf_out, rows, stream); break;
+            case 12: q_launch<12>(f, g, sums, sums_in, leaf_out, rows, stream, cshift); break;
+            case 8: q_launch<8>(f, g, sums, sums_in, leaf_out, rows, stream, cshift); break;
+            default: q_launch<4>(f, g, sums, sums_in, leaf_out, rows, stream, cshift); break;
         }
         TAHOE_HIP_TRY(hipGetLastError());
         first = false;

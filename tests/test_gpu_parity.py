@@ -195,7 +195,7 @@ def test_invalid_forests_are_rejected(env):
     with pytest.raises(ta.TahoeError) as e:
         f.set_strategy(ta.STRATEGY_ROWTILE)
     assert e.value.status == 7
-    # too wide for any LDS row tile: AUTO takes the quantised walk with feature codes read from L2 (GX form)
+    # too wide for any float32 row tile: AUTO takes the quantised walk (16-row u16 tiles, four trees per wave)
     assert f.get_strategy(100) == ta.STRATEGY_QRING and f.info().qring_walkers == 15
 
 
@@ -508,3 +508,34 @@ def test_wide_rows(env, T, D, C, R, leaf_prob):
     # no missing values at all: the single-compare fast path
     clean = ta.synth_data(R, C, seed=500 + R)
     run_case(env, nodes, T, D, C, clean, strategies=[ta.STRATEGY_QRING])
+
+
+def test_two_handles_on_two_streams_concurrently(env):
+    """Handles share no mutable global state (the reference keeps its strategy and device buffers in globals,
+    Struct.h:9-11): two forests of different shapes predicting back to back on two streams, several rounds in
+    flight before anything synchronises, each give their oracle's bits."""
+    ta, oracle, torch = env
+    a_nodes = ta.synth_forest(200, 10, 64, seed=101, leaf_prob=0.05)
+    b_nodes = ta.synth_forest(40, 6, 700, seed=102)
+    a_data = ta.synth_data(20_000, 64, seed=103, missing_prob=0.05, missing=MISSING)
+    b_data = ta.synth_data(3_000, 700, seed=104, missing_prob=0.05, missing=MISSING)
+    a, b = ta.Forest(a_nodes, 200, 10, 64, missing=MISSING), ta.Forest(b_nodes, 40, 6, 700, missing=MISSING)
+    a.reserve(20_000)
+    b.reserve(3_000)
+    ax, bx = torch.from_numpy(a_data).cuda(), torch.from_numpy(b_data).cuda()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs_a = [torch.empty(20_000, dtype=torch.float32, device="cuda") for _ in range(4)]
+    outs_b = [torch.empty(3_000, dtype=torch.float32, device="cuda") for _ in range(4)]
+    for i in range(4):
+        a.predict_raw(ax, outs_a[i], stream=sa)
+        b.predict_raw(bx, outs_b[i], stream=sb)
+    a.check(sa)
+    b.check(sb)
+    want_a = oracle.predict(a_nodes, 200, 10, a_data, MISSING, threads=8)[0]
+    want_b = oracle.predict(b_nodes, 40, 6, b_data, MISSING, threads=8)[0]
+    for i in range(4):
+        assert np.array_equal(bits(outs_a[i].cpu().numpy()), bits(want_a)), i
+        assert np.array_equal(bits(outs_b[i].cpu().numpy()), bits(want_b)), i
+    a.close()
+    b.close()

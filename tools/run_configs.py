@@ -76,9 +76,12 @@ def main():
     sample = np.unique(np.concatenate([np.arange(0, R, 2003), [R - 1]]))
     for name, T in (("K3", 1000), ("K4", 8000)):
         nodes = ta.synth_forest(T, D, C, seed=42)
+        tc = time.perf_counter()
         f = ta.Forest(nodes, T, D, C, missing=MISSING)
+        create_s = time.perf_counter() - tc
         ms, full = time_predict(f, x, steps=3, warmup=1)
         entry = {"shape": [T, D, C, R], "strategy": ta.STRATEGY_NAMES[f.get_strategy(R)], "ms": round(ms, 3),
+                 "create_s": round(create_s, 2), "device_MB": round(f.info().device_bytes / 1e6, 1),
                  "samples_per_s": round(R / ms * 1e3), "parity_sample_%d" % sample.size: check_dense(f, nodes, T, D, data, x, sample)}
         if name == "K4":
             per = ta.capi.tree_num_nodes(D)
