@@ -1305,6 +1305,16 @@ tahoe_status qring_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner,
     }
     // ---- cut the forest into tree groups whose features each see <= kQMaxTable distinct thresholds ----
     size_t lo = 0, gsize = T;
+    {
+        // first guess from the node counts per feature (an upper bound of the distinct thresholds): saves building
+        // and throwing away the tables of a forest that obviously needs several groups (K4: 8 s -> 4 s of create)
+        std::vector<size_t> per_feature((size_t)cols, 0);
+        for (size_t i = 0; i < T * f->n_inner; ++i)
+            if (h_real[i] && !std::isnan(h_inner[i].thr)) ++per_feature[h_inner[i].meta & 0x7fffffffu];
+        const size_t most = *std::max_element(per_feature.begin(), per_feature.end());
+        if (most > (size_t)kQMaxTable + kQMaxTable / 2)
+            gsize = std::max<size_t>(1, (size_t)((double)T * kQMaxTable / (double)most));
+    }
     while (lo < T) {
         size_t hi = std::min(T, lo + gsize);
         tahoe_qgroup g;
