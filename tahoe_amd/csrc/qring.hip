@@ -681,7 +681,11 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
         uint4 na_p[K] = {}, nb_p[K] = {};
         uint32_t bsel_p[K] = {};
         for (int t = wave; t < num_trees && !dead; t += NWALK) {
+#if defined(TAHOE_ABLATE) && (TAHOE_ABLATE & 2)
+            const bool more = false;  // timing-only build: every tree walks the first top
+#else
             const bool more = t + NWALK < num_trees;
+#endif
             if (more) prefetch_top(t + NWALK);
             uint32_t i[K];
     #pragma unroll
@@ -690,6 +694,9 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                 uint32_t node[K];
     #pragma unroll
                 for (int k = 0; k < K; ++k) node[k] = slot[1];
+                // Both children come with one ds_read_b64 issued beside the feature read, ahead of the compare.  (Reading
+                // only the chosen child afterwards -- half the LDS bytes, twice the round trips -- times the same to
+                // 0.5 %: neither LDS bandwidth nor LDS latency bounds this loop, see DESIGN.md.)
                 for (int l = 0; l < top_levels - 1; ++l) {
                     uint32_t xc[K];
                     uint2 pr[K];
@@ -734,7 +741,11 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
             for (int k = 0; k < K; ++k) {
                 const uint4 *bp = blocks + ((size_t)t * n_blocks + bsel[k]) * 2;
                 na_p[k] = bp[0];  // node0, node1, node2, 0
+#if defined(TAHOE_ABLATE) && (TAHOE_ABLATE & 1)
+                nb_p[k] = na_p[k];  // timing-only build: no leaf gather
+#else
                 nb_p[k] = bp[1];  // four leaf values
+#endif
                 bsel_p[k] = bsel[k];
             }
             if (more) commit_top();  // this wave's reads of its slot are done (in-order LDS)
