@@ -21,6 +21,7 @@
 
 #include <cfloat>
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -91,7 +92,7 @@ class BaseTahoeTest {
 
     int SetUp(float &speedup)
     {
-        float acc[6];
+        float *acc = last_acc;
         check(tahoe_stream_create(&stream), "tahoe_stream_create");
         printf("Loading model...\n");
         generate_forest_from_file();
@@ -102,6 +103,7 @@ class BaseTahoeTest {
         printf("Test on GPU...\n");
         init_forest();
         const float baseline = predict_on_gpu_baseline();
+        last_baseline = baseline;
         predict_on_gpu_strategies(acc);
         int algorithm = 0;
         float best = FLT_MAX;
@@ -202,6 +204,42 @@ class BaseTahoeTest {
         check(tahoe_stream_synchronize(stream), "tahoe_stream_synchronize");
     }
 
+    // Additions to the reference surface (machine-readable results, leaf-index dump).
+    // Per-(row, tree) leaf indices in the reference's heap numbering, rows x trees uint32, row-major.
+    bool dump_leaf_indices(const char *path)
+    {
+        const size_t n = (size_t)ps.num_rows * (size_t)ps.num_trees;
+        uint32_t *leaf_d = nullptr;
+        if (tahoe_device_alloc((void **)&leaf_d, n * sizeof(uint32_t), 0) != TAHOE_OK) return false;
+        std::vector<uint32_t> leaf(n);
+        bool ok = tahoe_forest_predict_leaf_idx(forest, leaf_d, nullptr, data_d, (size_t)ps.num_rows, stream) == TAHOE_OK &&
+                  tahoe_copy_to_host(leaf.data(), leaf_d, n * sizeof(uint32_t), stream) == TAHOE_OK &&
+                  tahoe_stream_synchronize(stream) == TAHOE_OK;
+        tahoe_device_free(leaf_d);
+        if (!ok) return false;
+        FILE *fp = fopen(path, "wb");
+        if (!fp) return false;
+        ok = fwrite(leaf.data(), sizeof(uint32_t), n, fp) == n;
+        return fclose(fp) == 0 && ok;
+    }
+
+    bool write_result_json(const char *path, int best_by_run, float speedup)
+    {
+        FILE *fp = fopen(path, "w");
+        if (!fp) return false;
+        fprintf(fp, "{\"model\": \"%s\", \"data\": \"%s\", \"num_trees\": %d, \"depth\": %d, \"num_rows\": %d, \"num_cols\": %d, ",
+                ps.input_model_file, ps.input_data_file, ps.num_trees, ps.depth, ps.num_rows, ps.num_cols);
+        fprintf(fp, "\"baseline_us_per_sample\": %.6f, \"strategy_us_per_sample\": [", last_baseline);
+        for (int i = 0; i < 5; ++i) {
+            if (last_acc[i] == FLT_MAX)
+                fprintf(fp, "null%s", i < 4 ? ", " : "");
+            else
+                fprintf(fp, "%.6f%s", last_acc[i], i < 4 ? ", " : "");
+        }
+        fprintf(fp, "], \"best_strategy\": %d, \"auto_strategy\": %d, \"speedup\": %.4f}\n", best_by_run, auto_strategy, speedup);
+        return fclose(fp) == 0;
+    }
+
     TahoeTestParams ps;
     std::vector<dense_node_t> nodes;
     std::vector<float> data_h;
@@ -211,6 +249,8 @@ class BaseTahoeTest {
     void *stream = nullptr;  // hipStream_t behind the C ABI
     tahoe_forest *forest = nullptr;
     int selected_algorithm = 0;
+    float last_acc[6] = {0, 0, 0, 0, 0, 0};  // us/sample of strategies 1..5 from the last SetUp (FLT_MAX = not suitable)
+    float last_baseline = 0.0f;              // us/sample of the baseline run
     int auto_strategy = 0;  // what TAHOE_STRATEGY_AUTO resolves to for this shape (1-based, as SetUp returns)
 
    private:

@@ -23,6 +23,12 @@ int main(int argc, char *argv[])
     else
         std::cout << "Performance model predicts incorrectly" << std::endl;
     std::cout << "Tahoe brings " << speedup << "x speedup." << std::endl;
+    // beyond the reference's protocol: TAHOE_RESULT_JSON=<file> (machine-readable summary of this run),
+    // TAHOE_LEAF_DUMP=<file> (uint32 leaf index of every (row, tree), reference heap numbering)
+    if (const char *path = getenv("TAHOE_RESULT_JSON"))
+        if (!pTest->write_result_json(path, best_by_run, speedup)) fprintf(stderr, "cannot write %s\n", path);
+    if (const char *path = getenv("TAHOE_LEAF_DUMP"))
+        if (!pTest->dump_leaf_indices(path)) fprintf(stderr, "cannot write %s: %s\n", path, tahoe_last_error());
     pTest->Free();
     delete pTest;
     return 0;

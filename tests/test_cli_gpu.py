@@ -26,6 +26,31 @@ def test_cli_protocol(built, case):
     assert "Using strategy 5" in out or "Strategy 5 is not suitable for this case." in out
 
 
+def test_cli_result_json_and_leaf_dump(built, tmp_path):
+    """TAHOE_RESULT_JSON / TAHOE_LEAF_DUMP: the machine-readable summary, and per-(row, tree) leaf indices that equal
+    the oracle's on the golden case."""
+    import json
+
+    import numpy as np
+
+    from oracle import oracle
+
+    exe = os.path.join(ROOT, "tahoe_amd", "host", "Tahoe")
+    g = os.path.join(ROOT, "tests", "golden", "susy_like_c18")
+    js, leaf = tmp_path / "r.json", tmp_path / "leaf.bin"
+    env = dict(os.environ, TAHOE_RESULT_JSON=str(js), TAHOE_LEAF_DUMP=str(leaf))
+    r = subprocess.run([exe, g + ".model.txt", g + ".data.txt"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    res = json.loads(js.read_text())
+    assert res["num_cols"] == 18 and len(res["strategy_us_per_sample"]) == 5 and 1 <= res["best_strategy"] <= 5
+    assert res["speedup"] > 0 and res["baseline_us_per_sample"] > 0
+    nodes, T, D = oracle.load_model(g + ".model.txt")
+    data, missing = oracle.load_data(g + ".data.txt")
+    _, want_leaf = oracle.predict(nodes, T, D, data, missing, want_leaf=True)
+    got = np.fromfile(str(leaf), dtype=np.uint32).reshape(data.shape[0], T)
+    assert np.array_equal(got, want_leaf)
+
+
 def test_cli_unreadable_file_exits_1(built):
     exe = os.path.join(ROOT, "tahoe_amd", "host", "Tahoe")
     r = subprocess.run([exe, "/nonexistent/model", "/nonexistent/data"], capture_output=True, text=True, timeout=60)
