@@ -116,6 +116,18 @@ def test_sparse_walk_on_gpu(ta):
         leaf, sums = f.predict_leaf_idx(torch.from_numpy(xs).cuda())
         assert np.array_equal(sums.cpu().numpy().view(np.uint32), want.view(np.uint32))
         assert np.array_equal(leaf.cpu().numpy().view(np.uint32), want_leaf)
+    # a tree with more than 65536 reachable nodes does not fit the compact 16-bit links: the 12-byte-node kernels serve
+    big, big_tr = ta.capi.synth_sparse_forest(3, 8, 16, 17, 0.0, 300_000, 77)
+    assert np.diff(np.append(big_tr, big.size)).max() > 65536
+    bx = ta.synth_data(500, 8, seed=78, missing_prob=0.05, missing=MISSING)
+    want, want_leaf = oracle.sparse_predict(big, big_tr, bx, MISSING, want_leaf=True, threads=8)
+    f = ta.capi.SparseForest(big, big_tr, 8, missing=MISSING)
+    assert f.get_strategy(500) == ta.STRATEGY_ROWTILE
+    with pytest.raises(ta.TahoeError):
+        f.set_strategy(ta.STRATEGY_TILEBLOCK)
+    leaf, sums = f.predict_leaf_idx(torch.from_numpy(bx).cuda())
+    assert np.array_equal(sums.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(leaf.cpu().numpy().view(np.uint32), want_leaf)
     # malformed forests are rejected (the reference would walk out of the arrays or spin)
     bad = sn.copy()
     first_inner = int(np.flatnonzero((bad["bits"].view(np.uint32) >> 31) == 0)[0])
