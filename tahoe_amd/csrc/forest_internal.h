@@ -75,6 +75,17 @@ struct tahoe_forest {
 
 namespace tahoe {
 
+// Ring flags: relaxed workgroup-scope accesses (plain ds_read/ds_write that the compiler neither caches
+// in a register nor reorders across the asm memory barriers around them).
+__device__ __forceinline__ uint32_t lds_flag_load(const uint32_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_flag_store(uint32_t *p, uint32_t v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is per function and process-wide, not per handle: always raise it to
 // the device limit (less the kernel's static LDS), so that handles of different shapes can coexist in one process.
 inline hipError_t allow_max_lds(const void *fn, int limit)

@@ -30,17 +30,6 @@
 
 namespace tahoe {
 
-// Ring flags: relaxed workgroup-scope accesses (plain ds_read/ds_write that the compiler neither caches
-// in a register nor reorders across the asm memory barriers around them).
-__device__ __forceinline__ uint32_t lds_flag_load(const uint32_t *p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void lds_flag_store(uint32_t *p, uint32_t v)
-{
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
 // The branch rule on codes: right <=> (missing ? !def_left : code(x) >= code(thr)).  Written on wave
 // masks: three v_cmp into SGPR pairs, three SALU ops, and the result is used directly as the lane
 // predicate of v_cndmask / v_addc (hipcc's ?: form materialises both booleans in VGPRs: 6 more VALU).

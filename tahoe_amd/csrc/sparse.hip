@@ -107,27 +107,38 @@ __global__ void __launch_bounds__(kBlock) sparse_kernel(const tahoe_sparse_node 
     }
 }
 
-// Tree tops in LDS.  NW waves share one 64-row float32 tile and split the trees round-robin; each wave stages
+// Tree tops in LDS.  NW - 1 walker waves share one 64-row float32 tile and split the trees round-robin; each stages
 // the first kSTop nodes of its tree (breadth-first order: the top levels) into a private 4 KiB LDS slot with four
 // coalesced 16-byte loads per lane, issued before the previous tree is walked and committed after it.  A walk
 // reads nodes from the slot while its position is < kSTop and gathers from global memory below.  The gathers are
 // what bounds the plain kernel (64 lanes = 64 cache lines per step through the texture path, 12-byte nodes);
-// here only the steps below the top pay them, with 8-byte nodes.  Sums: as above, the row's owner lane adds the
-// NW leaf values of a round in tree order.
-constexpr int kSTop = 512;  // nodes per slot (8 B each)
+// here only the steps below the top pay them, with 8-byte nodes.
+// Sums: irregular trees take 4 to 24 steps, so a barrier per round of trees would make every wave wait for the
+// deepest tree of the round.  Instead the walkers publish leaf values through an LDS ring (vals, then a ready flag;
+// LDS operations of one CU complete in order) and the last wave adds them in tree order, exactly the scheme of
+// qring_kernel: walkers wait only for `consumed` (ring capacity), the consumer only for trees whose walkers
+// cannot be blocked; every spin is bounded and raises the error flag.
+constexpr int kSTop = 512;    // nodes per slot (8 B each)
+constexpr int kSRing = 32;    // ring entries (trees)
+constexpr int kSBatch = 16;   // trees the consumer takes per poll
+constexpr int kSSpinLimit = 1 << 22;
 template <int NW, bool WRITE_LEAF>
 __global__ void __launch_bounds__(NW * 64) sparse_top_kernel(const uint2 *__restrict__ cnodes, const int32_t *__restrict__ ctrees,
                                                              const uint32_t *__restrict__ corig, const float *__restrict__ data,
                                                              float *__restrict__ sums, uint32_t *__restrict__ leaf_out, size_t rows,
-                                                             int cols, int num_trees, float missing, int vec4_ok)
+                                                             int cols, int num_trees, float missing, int vec4_ok,
+                                                             int *__restrict__ error_flag)
 {
+    constexpr int NWALK = NW - 1;
+    static_assert(kSRing >= 2 * kSBatch && kSRing > NWALK, "ring too small");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float *tile = reinterpret_cast<float *>(smem);
     unsigned char *slots = smem + (size_t)cols * kTileRows * sizeof(float);
-    uint2 *slot = reinterpret_cast<uint2 *>(slots + (size_t)wave * (kSTop * 8));
-    float *vals = reinterpret_cast<float *>(slots + (size_t)NW * (kSTop * 8));
+    float *ring_vals = reinterpret_cast<float *>(slots + (size_t)NWALK * (kSTop * 8));
+    uint32_t *ring_ready = reinterpret_cast<uint32_t *>(ring_vals + kSRing * kTileRows);
+    uint32_t *consumed = ring_ready + kSRing;
     const size_t row0 = (size_t)blockIdx.x * kTileRows;
     const size_t row = row0 + lane;
     const bool row_ok = row < rows;
@@ -144,9 +155,42 @@ __global__ void __launch_bounds__(NW * 64) sparse_top_kernel(const uint2 *__rest
     } else {
         for (int f = wave; f < cols; f += NW) tile[f * kTileRows + lane] = row_ok ? xrow[f] : 0.0f;
     }
+    if (threadIdx.x < kSRing) ring_ready[threadIdx.x] = 0u;
+    if (threadIdx.x == kSRing) *consumed = 0u;
+
+    if (wave == NWALK) {
+        // ================= consumer: lane = row, trees in order =================
+        __syncthreads();
+        float sum = 0.0f;
+        bool dead = false;
+        for (int t0 = 0; t0 < num_trees && !dead; t0 += kSBatch) {
+            const int nb = min(kSBatch, num_trees - t0);
+            int spins = 0;
+            for (;;) {
+                const bool ok = lane >= nb || lds_flag_load(&ring_ready[(t0 + lane) % kSRing]) == (uint32_t)(t0 + lane + 1);
+                if (__ballot(ok) == ~0ull) break;
+                if (++spins > kSSpinLimit) {
+                    dead = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (dead) break;
+            asm volatile("" ::: "memory");  // the values are read after the flags
+            for (int j = 0; j < nb; ++j) sum += ring_vals[((t0 + j) % kSRing) * kTileRows + lane];  // tree order
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) lds_flag_store(consumed, (uint32_t)(t0 + nb));
+        }
+        if (dead && lane == 0) atomicOr(error_flag, 1);
+        if (sums && row_ok) sums[row] = sum;
+        return;
+    }
+
+    // ================= walkers =================
+    uint2 *slot = reinterpret_cast<uint2 *>(slots + (size_t)wave * (kSTop * 8));
     // top of tree t: uint4 j * 64 + lane holds nodes 2 * (j * 64 + lane) and the next; clamped loads stay inside
     // the tree's (16-byte padded) node range, slots keep whatever the clamp fetched beyond it (never reached)
-    uint4 pf0, pf1, pf2, pf3;
+    uint4 pf0, pf1, pf2, pf3;  // named registers: an array, even under full unrolling, costs 60 % (measured)
     auto prefetch_top = [&](int t) {
         const int32_t lo = ctrees[t], n = ctrees[t + 1] - lo;  // n is even (padded)
         const uint4 *src = reinterpret_cast<const uint4 *>(cnodes + lo);
@@ -164,54 +208,53 @@ __global__ void __launch_bounds__(NW * 64) sparse_top_kernel(const uint2 *__rest
         s[3 * 64 + lane] = pf3;
     };
     if (wave < num_trees) prefetch_top(wave);
-    __syncthreads();  // the tile
-    constexpr int RPW = kTileRows / NW;  // rows summed by each wave's first lanes
-    float sum = 0.0f;
-    const int rounds = (num_trees + NW - 1) / NW;
-    for (int r = 0; r < rounds; ++r) {
-        const int t = r * NW + wave;
-        float v = 0.0f;
-        if (t < num_trees) {
-            commit_top();  // own slot, own wave: LDS operations of one wave complete in order
-            if (t + NW < num_trees) prefetch_top(t + NW);
-            const uint2 *root = cnodes + ctrees[t];
-            uint32_t curr = 0;
-            for (;;) {  // create() guarantees children after their parent and inside the tree: the walk terminates
-                uint2 n;
-                if (curr < (uint32_t)kSTop)
-                    n = slot[curr];
-                else
-                    n = root[curr];
-                const uint32_t left = n.y >> 16;
-                if (left == 0u) {
-                    v = __uint_as_float(n.x);
+    __syncthreads();  // the tile and the ring state
+    bool dead = false;
+    for (int t = wave; t < num_trees && !dead; t += NWALK) {
+        commit_top();  // own slot, own wave: LDS operations of one wave complete in order
+        if (t + NWALK < num_trees) prefetch_top(t + NWALK);
+        const uint2 *root = cnodes + ctrees[t];
+        uint32_t curr = 0;
+        float v;
+        for (;;) {  // create() guarantees children after their parent and inside the tree: the walk terminates
+            uint2 n;
+            if (curr < (uint32_t)kSTop)
+                n = slot[curr];
+            else
+                n = root[curr];
+            const uint32_t left = n.y >> 16;
+            if (left == 0u) {
+                v = __uint_as_float(n.x);
+                break;
+            }
+            const float x = tile[(n.y & 0x7fffu) * kTileRows + lane];
+            curr = left + go_right(x, __uint_as_float(n.x), (n.y & 0x8000u) != 0u, missing);
+        }
+        if (WRITE_LEAF) {
+            if (row_ok) leaf_out[row * (size_t)num_trees + t] = corig[ctrees[t] + curr];
+        }
+        if (t >= kSRing) {  // ring entry still in use by tree t - kSRing?
+            int spins = 0;
+            while (lds_flag_load(consumed) < (uint32_t)(t - kSRing + 1)) {
+                if (++spins > kSSpinLimit) {
+                    dead = true;
                     break;
                 }
-                const float x = tile[(n.y & 0x7fffu) * kTileRows + lane];
-                curr = left + go_right(x, __uint_as_float(n.x), (n.y & 0x8000u) != 0u, missing);
-            }
-            if (WRITE_LEAF) {
-                if (row_ok) leaf_out[row * (size_t)num_trees + t] = corig[ctrees[t] + curr];
+                __builtin_amdgcn_s_sleep(1);
             }
         }
-        float *vb = vals + (size_t)(r & 1) * NW * kTileRows;
-        vb[wave * kTileRows + lane] = v;
-        __syncthreads();
-        if (lane < RPW) {
-            const int rr = RPW * wave + lane;
-            const int nt = min(NW, num_trees - r * NW);
-            for (int j = 0; j < nt; ++j) sum += vb[j * kTileRows + rr];  // tree order
-        }
+        const int e = t % kSRing;
+        ring_vals[e * kTileRows + lane] = v;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // values before the flag (in-order LDS)
+        if (lane == 0) lds_flag_store(&ring_ready[e], (uint32_t)(t + 1));
     }
-    if (sums && lane < RPW) {
-        const size_t orow = row0 + RPW * wave + lane;
-        if (orow < rows) sums[orow] = sum;
-    }
+    if (dead && lane == 0) atomicOr(error_flag, 1);
 }
 
 static long long sparse_top_lds(const tahoe_forest *f, int nw)
 {
-    return (long long)f->p.num_cols * kTileRows * 4 + (long long)nw * kSTop * 8 + 2LL * nw * kTileRows * 4;
+    return (long long)f->p.num_cols * kTileRows * 4 + (long long)(nw - 1) * kSTop * 8 + (long long)kSRing * kTileRows * 4 +
+           (kSRing + 1) * 4LL;
 }
 
 // waves per workgroup of sparse_top_kernel for this handle; 0 = that form is unavailable
@@ -242,7 +285,7 @@ tahoe_status sparse_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, con
         const int lds = (int)sparse_top_lds(f, nw);
 #define TAHOE_SPARSE_TOP(NW_, LEAF_)                                                                                     \
     hipLaunchKernelGGL((sparse_top_kernel<NW_, LEAF_>), dim3(grid), dim3(NW_ * 64), lds, stream, sp->cnodes, sp->ctrees, \
-                       sp->corig, data, sums, leaf_out, rows, f->p.num_cols, f->p.num_trees, f->p.missing, vec4_ok)
+                       sp->corig, data, sums, leaf_out, rows, f->p.num_cols, f->p.num_trees, f->p.missing, vec4_ok, f->error_flag)
         if (nw == 16) {
             if (leaf_out)
                 TAHOE_SPARSE_TOP(16, true);
@@ -367,6 +410,8 @@ tahoe_status tahoe_sparse_forest_create(tahoe_forest **out, const int32_t *trees
         return bail(e, "hipMemcpy(nodes)");
     if (p->num_trees && (e = hipMemcpy(sp->trees, trees, (size_t)p->num_trees * sizeof(int32_t), hipMemcpyHostToDevice)) != hipSuccess)
         return bail(e, "hipMemcpy(trees)");
+    if ((e = hipMalloc(reinterpret_cast<void **>(&f->error_flag), sizeof(int))) != hipSuccess) return bail(e, "hipMalloc(error_flag)");
+    if ((e = hipMemset(f->error_flag, 0, sizeof(int))) != hipSuccess) return bail(e, "hipMemset(error_flag)");
     if (sparse_tile_fits(f)) {
         if ((e = allow_max_lds(reinterpret_cast<const void *>(&sparse_kernel<true, false>), f->lds_limit)) != hipSuccess)
             return bail(e, "hipFuncSetAttribute(sparse)");
