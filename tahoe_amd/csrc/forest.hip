@@ -752,10 +752,28 @@ static void launch_tilering(tahoe_forest *f, float *sums, uint32_t *leaf_out, co
                            f->p.num_trees, f->depth, f->top_levels, stride, f->p.missing, vec4_ok, f->error_flag);
 }
 
+// A process that drives several GPUs (one handle per device) calls predict with any device current: the launches
+// must be issued with the handle's device current.  Restores the caller's device on scope exit.
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int want)
+    {
+        int cur = -1;
+        if (hipGetDevice(&cur) == hipSuccess && cur != want && hipSetDevice(want) == hipSuccess) prev = cur;
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 static tahoe_status launch_traversal(tahoe_forest *f, float *sums, uint32_t *leaf_out, const float *data,
                                      size_t rows, hipStream_t stream)
 {
     if (rows == 0) return TAHOE_OK;
+    DeviceGuard on_device(f->device);
     const int strategy = resolve_strategy(f, rows);
     if ((rows + 63) / 64 > 0x7fffffffu) return fail(TAHOE_ERR_INVALID_ARG, "too many rows for one launch: %zu", rows);
     const bool timed = f->profiling && f->prof_count < f->ev_start.size();
@@ -1085,6 +1103,7 @@ tahoe_status tahoe_forest_predict(tahoe_forest *f, float *preds_dev, const float
 {
     if (!f || (rows && (!preds_dev || !data_dev)))
         return fail(TAHOE_ERR_INVALID_ARG, "tahoe_forest_predict: null argument");
+    DeviceGuard on_device(f->device);
     tahoe_status s = launch_traversal(f, preds_dev, nullptr, data_dev, rows, (hipStream_t)stream);
     if (s != TAHOE_OK) return s;
     return launch_transform(preds_dev, rows, f->p.output, f->p.num_trees, f->p.threshold, f->p.global_bias,

@@ -51,6 +51,18 @@ def test_cli_result_json_and_leaf_dump(built, tmp_path):
     assert np.array_equal(got, want_leaf)
 
 
+@pytest.mark.parametrize("args", [["1"], ["--emulate", "3"], ["--emulate", "7"]])
+def test_sharded_host(built, args):
+    """./TahoeSharded: the C++ tree-sharding host (one process, a forest shard per device, one ncclAllReduce per
+    batch).  A 1-GPU box can check the RCCL path with a single shard (bit-exact) and the partition logic with shards
+    emulated on device 0 (partials added in shard order, 1e-6 relative)."""
+    exe = os.path.join(ROOT, "tahoe_amd", "host", "TahoeSharded")
+    g = os.path.join(ROOT, "tests", "golden", "susy_like_c18")
+    r = subprocess.run([exe, g + ".model.txt", g + ".data.txt"] + args, capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Results are correct" in r.stdout and "Exec.Time/Sample with" in r.stdout
+
+
 def test_cli_unreadable_file_exits_1(built):
     exe = os.path.join(ROOT, "tahoe_amd", "host", "Tahoe")
     r = subprocess.run([exe, "/nonexistent/model", "/nonexistent/data"], capture_output=True, text=True, timeout=60)
