@@ -30,63 +30,6 @@
 
 namespace tahoe {
 
-// The branch rule on codes: right <=> (missing ? !def_left : code(x) >= code(thr)).  Written on wave
-// masks: three v_cmp into SGPR pairs, three SALU ops, and the result is used directly as the lane
-// predicate of v_cndmask / v_addc (hipcc's ?: form materialises both booleans in VGPRs: 6 more VALU).
-// MS = false is the fast path for row chunks in which the quantise pass met no missing value (it
-// reports that per chunk): the rule is then the single compare.
-// NARROW (num_cols <= 256): node = code << 16 | fid << 8 | def_left, so that the feature column's LDS offset
-// (fid * 256) is a bit field of the node word and one v_bfi forms the read address (q_xread).
-template <bool MS, bool NARROW>
-__device__ __forceinline__ uint64_t q_right_mask(uint32_t xc, uint32_t node)
-{
-    const uint64_t ge = __builtin_amdgcn_uicmp(xc, NARROW ? node >> 16 : node & 0xFFFFu, 35 /* ICMP_UGE */);
-    if (!MS) return ge;
-    const uint64_t ms = __builtin_amdgcn_uicmp(xc, kCodeMissing, 32 /* ICMP_EQ */);
-    const uint64_t ndl = NARROW ? __builtin_amdgcn_uicmp(node & 0xFFu, 0u, 32 /* ICMP_EQ: def_left clear */)
-                                : __builtin_amdgcn_sicmp((int)node, -1, 38 /* ICMP_SGT: bit 31 (def_left) clear */);
-    return (ge & ~ms) | (ms & ndl);
-}
-template <bool MS, bool NARROW>
-__device__ __forceinline__ bool q_go_right(uint32_t xc, uint32_t node)
-{
-    return __builtin_amdgcn_inverse_ballot_w64(q_right_mask<MS, NARROW>(xc, node));
-}
-// i <- 2i + (lane's bit of mask): one v_addc with the mask as carry-in
-__device__ __forceinline__ uint32_t q_descend(uint32_t i, uint64_t right_mask)
-{
-    uint32_t r;
-    uint64_t carry_out;
-    asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(r), "=&s"(carry_out) : "v"(i), "s"(right_mask));
-    return r;
-}
-// The u16 code of feature fid(node) for this lane's row.  `posb` = LDS byte address of the row's slot in
-// feature column 0 (tile base + position); a column is 256 bytes.  The address is formed as an LDS
-// (address-space 3) integer, fid * 256 + posb: v_bfe + v_lshl_add, two VALU.  (Going through the generic
-// `tile` pointer costs a third: hipcc adds the LDS base, a link-time 0, with its own v_add.)
-// LDSX = false ("GX" form, for rows too wide for an LDS tile): the same 256-byte columns are read straight from
-// the quantised tile in global memory (L2-resident: one 128-row tile of 3072 columns is 768 KiB); `gx` = the
-// tile's base, posb = byte position inside a column.
-typedef const uint16_t __attribute__((address_space(3))) *lds_u16_ptr;
-template <bool LDSX, bool NARROW, int CSHIFT = 8>
-__device__ __forceinline__ uint32_t q_xread(const unsigned char *gx, uint32_t node, uint32_t posb)
-{
-    static_assert(!NARROW || CSHIFT == 8, "the NARROW layout is defined for 256-byte feature columns");
-    if (LDSX && NARROW) {
-        // the tile starts at LDS address 0 (checked at kernel entry) and posb < 256: address = node[15:8] : posb[7:0]
-        uint32_t addr;
-        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(addr) : "s"(0xFF00u), "v"(node), "v"(posb));
-        return *reinterpret_cast<lds_u16_ptr>(addr);
-    }
-    if (LDSX) {
-        uint32_t addr;  // asm: hipcc re-canonicalises the C form into shift + and + add
-        asm("v_bfe_u32 %0, %1, 16, 15\n\tv_lshl_add_u32 %0, %0, %3, %2" : "=&v"(addr) : "v"(node), "v"(posb), "n"(CSHIFT));
-        return *reinterpret_cast<lds_u16_ptr>(addr);
-    }
-    if (NARROW) return *reinterpret_cast<const uint16_t *>(gx + (node & 0xFF00u) + posb);
-    return *reinterpret_cast<const uint16_t *>(gx + (((node >> 16) & 0x7fffu) << CSHIFT) + posb);
-}
-
 // ------------------------------------------------------------------------------------------------
 // (2) the walk.  Dynamic LDS: tile [cols][128] u16 | NWALK slots of (4 << L) bytes | ring [16][128] f32 |
 // ready[16] | consumed.
@@ -770,7 +713,7 @@ int qring_groups(const tahoe_forest *f) { return f->q ? (int)f->q->groups.size()
 tahoe_status qring_reserve(tahoe_forest *f, size_t rows)
 {
     tahoe_qstate *q = f->q;
-    if (!q || qring_walkers(f) == 0) return TAHOE_OK;
+    if (!q) return TAHOE_OK;  // no quantised form on this handle
     const size_t tiles = (rows + kQRows - 1) / kQRows;
     if (tiles * kQRows <= q->xq_rows) return TAHOE_OK;
     if (q->xq) {
