@@ -21,6 +21,12 @@
  * copy of the batch in a grow-only workspace; a batch larger than any before grows it (allocation +
  * device synchronisation) unless tahoe_forest_reserve sized it beforehand.
  *
+ * Handles share no global state and different handles may be used from different threads and streams
+ * at the same time.  One handle serves one predict at a time: its workspace is reused by the next call,
+ * so calls on the same handle must be ordered on one stream (or separated by a synchronisation).  A
+ * process that drives several GPUs keeps one handle per device; predict switches to the handle's
+ * device for its launches and restores the caller's.
+ *
  * There is no CPU fallback: every compute entry point fails with TAHOE_ERR_NO_DEVICE when no
  * gfx950 device is usable.
  */
