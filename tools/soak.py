@@ -1,0 +1,34 @@
+"""Soak: many back-to-back predicts of the ring kernels (K3 QRING, K2 wide form, K5 sparse), then tahoe_forest_check
+(a bounded LDS wait that ever timed out raises) and a bit-for-bit comparison of the last result with the first."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tahoe_amd as ta
+
+def soak(name, f, x, n):
+    out = torch.empty(x.shape[0], dtype=torch.float32, device="cuda")
+    f.predict_raw(x, out)
+    torch.cuda.synchronize()
+    first = out.cpu().numpy().copy()
+    t = time.perf_counter()
+    for _ in range(n):
+        f.predict_raw(x, out)
+    f.check()
+    dt = time.perf_counter() - t
+    same = np.array_equal(out.cpu().numpy().view(np.uint32), first.view(np.uint32))
+    print(f"{name}: {n} predicts, {dt / n * 1e3:.3f} ms each, error flag clear, last == first: {same}")
+    assert same
+
+x = torch.from_numpy(ta.synth_data(1_000_000, 256, seed=43)).cuda()
+f = ta.Forest(ta.synth_forest(1000, 12, 256, seed=42), 1000, 12, 256, missing=-999.0)
+soak("K3 qring", f, x, 300)
+f.close()
+sn, tr = ta.capi.synth_sparse_forest(2000, 256, 4, 24, 0.32, 65535, 44)
+f = ta.capi.SparseForest(sn, tr, 256, missing=-999.0)
+soak("K5 sparse ring", f, x[:200_000].contiguous(), 100)
+f.close()
+del x
+x = torch.from_numpy(ta.synth_data(100_000, 3072, seed=22)).cuda()
+f = ta.Forest(ta.synth_forest(500, 8, 3072, seed=21), 500, 8, 3072, missing=-999.0)
+soak("K2 wide", f, x, 300)
+f.close()
