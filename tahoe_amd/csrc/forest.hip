@@ -31,6 +31,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <mutex>
 #include <vector>
 
 #include "forest_internal.h"
@@ -934,56 +935,79 @@ tahoe_status tahoe_forest_create(tahoe_forest **out, const tahoe_dense_node *nod
     std::vector<InnerNode> h_inner(T * f->n_inner);
     std::vector<float> h_leaf(T * f->n_leaf);
     std::vector<uint32_t> h_orig(T * f->n_leaf);
-    std::vector<int64_t> inherit(all_nodes);
     std::vector<unsigned char> h_real(T * f->n_inner, 0);  // heap records that exist in the original tree
-    int max_fid = 0;
-    for (size_t t = 0; t < T; ++t) {
-        const tahoe_dense_node *tree = nodes + t * src_nodes;
-        for (size_t i = 0; i < all_nodes; ++i) {
-            const int64_t up = i ? inherit[(i - 1) / 2] : -1;
-            int fid = 0, def_left = 0, is_leaf = 0;
-            float value = 0.0f;
-            if (up >= 0) {
-                inherit[i] = up;  // below a leaf: unreachable in the original tree
-            } else {
-                // i < src_nodes here: a node without a leaf above it is at most on the original bottom
-                // level, because the check below rejects non-leaves there.
-                tahoe_decode_node(&tree[i], &value, nullptr, &fid, &def_left, &is_leaf);
-                if (is_leaf) {
-                    inherit[i] = (int64_t)i;
+    // trees are independent: normalise them on several host threads; the first invalid node (in tree order) wins
+    struct Bad {
+        size_t tree = SIZE_MAX, node = 0;
+        int kind = 0, fid = 0;  // 1: reachable bottom-level node is not a leaf, 2: fid >= num_cols
+    };
+    std::vector<Bad> bad_of;
+    std::vector<int> max_fid_of;
+    std::mutex collect;
+    const int num_cols = p->num_cols;
+    const size_t n_inner = f->n_inner, n_leaf = f->n_leaf;
+    parallel_for(T, 8, [&, n_inner, n_leaf, num_cols](size_t t_lo, size_t t_hi) {
+        std::vector<int64_t> inherit(all_nodes);
+        Bad bad;
+        int max_fid_local = 0;
+        for (size_t t = t_lo; t < t_hi && bad.kind == 0; ++t) {
+            const tahoe_dense_node *tree = nodes + t * src_nodes;
+            for (size_t i = 0; i < all_nodes; ++i) {
+                const int64_t up = i ? inherit[(i - 1) / 2] : -1;
+                int fid = 0, def_left = 0, is_leaf = 0;
+                float value = 0.0f;
+                if (up >= 0) {
+                    inherit[i] = up;  // below a leaf: unreachable in the original tree
                 } else {
-                    inherit[i] = -1;
-                    if (2 * i + 2 >= src_nodes) {
-                        delete f;
-                        return fail(TAHOE_ERR_INVALID_FOREST,
-                                    "tree %zu: reachable bottom-level node %zu is not a leaf (the reference would "
-                                    "walk out of the tree)", t, i);
+                    // i < src_nodes here: a node without a leaf above it is at most on the original bottom
+                    // level, because the check below rejects non-leaves there.
+                    tahoe_decode_node(&tree[i], &value, nullptr, &fid, &def_left, &is_leaf);
+                    if (is_leaf) {
+                        inherit[i] = (int64_t)i;
+                    } else {
+                        inherit[i] = -1;
+                        if (2 * i + 2 >= src_nodes || fid >= num_cols) {
+                            bad.tree = t;
+                            bad.node = i;
+                            bad.kind = 2 * i + 2 >= src_nodes ? 1 : 2;
+                            bad.fid = fid;
+                            break;
+                        }
+                        max_fid_local = std::max(max_fid_local, fid);
                     }
-                    if (fid >= p->num_cols) {
-                        delete f;
-                        return fail(TAHOE_ERR_INVALID_FOREST, "tree %zu node %zu: fid %d >= num_cols %d", t, i, fid,
-                                    p->num_cols);
-                    }
-                    max_fid = std::max(max_fid, fid);
                 }
-            }
-            if (i < f->n_inner) {
-                InnerNode &n = h_inner[t * f->n_inner + i];
-                if (inherit[i] >= 0) {
-                    n.thr = 0.0f;  // padding below a leaf: either child leads to the same value
-                    n.meta = 0u;
+                if (i < n_inner) {
+                    InnerNode &n = h_inner[t * n_inner + i];
+                    if (inherit[i] >= 0) {
+                        n.thr = 0.0f;  // padding below a leaf: either child leads to the same value
+                        n.meta = 0u;
+                    } else {
+                        n.thr = value;
+                        n.meta = (uint32_t)fid | (def_left ? 0x80000000u : 0u);
+                        h_real[t * n_inner + i] = 1;
+                    }
                 } else {
-                    n.thr = value;
-                    n.meta = (uint32_t)fid | (def_left ? 0x80000000u : 0u);
-                    h_real[t * f->n_inner + i] = 1;
+                    const size_t b = t * n_leaf + (i - n_inner);
+                    h_leaf[b] = tree[inherit[i]].val;
+                    h_orig[b] = (uint32_t)inherit[i];
                 }
-            } else {
-                const size_t b = t * f->n_leaf + (i - f->n_inner);
-                h_leaf[b] = tree[inherit[i]].val;
-                h_orig[b] = (uint32_t)inherit[i];
             }
         }
+        std::lock_guard<std::mutex> lock(collect);
+        if (bad.kind) bad_of.push_back(bad);
+        max_fid_of.push_back(max_fid_local);
+    });
+    if (!bad_of.empty()) {
+        const Bad bad = *std::min_element(bad_of.begin(), bad_of.end(), [](const Bad &x, const Bad &y) { return x.tree < y.tree; });
+        delete f;
+        if (bad.kind == 1)
+            return fail(TAHOE_ERR_INVALID_FOREST,
+                        "tree %zu: reachable bottom-level node %zu is not a leaf (the reference would walk out of the tree)",
+                        bad.tree, bad.node);
+        return fail(TAHOE_ERR_INVALID_FOREST, "tree %zu node %zu: fid %d >= num_cols %d", bad.tree, bad.node, bad.fid, num_cols);
     }
+    int max_fid = 0;
+    for (int m : max_fid_of) max_fid = std::max(max_fid, m);
     f->bits_bytes = reference_bits_bytes(max_fid);
 
     // ---- TILEBLOCK views: SoA tops and 32-byte bottom blocks ----
@@ -997,8 +1021,9 @@ tahoe_status tahoe_forest_create(tahoe_forest **out, const tahoe_dense_node *nod
         const size_t n_blocks = (size_t)1 << (De - 2);
         const size_t first = n_blocks - 1;
         h_blocks.resize(T * n_blocks * 2);
-        for (size_t t = 0; t < T; ++t) {
-            const InnerNode *in = &h_inner[t * f->n_inner];
+        parallel_for(T, 8, [&, n_inner, n_leaf](size_t t_lo, size_t t_hi) {
+        for (size_t t = t_lo; t < t_hi; ++t) {
+            const InnerNode *in = &h_inner[t * n_inner];
             float *thr = reinterpret_cast<float *>(&h_top[t * stride]);
             uint16_t *meta = reinterpret_cast<uint16_t *>(&h_top[t * stride + meta_off]);
             for (int i = 0; i < n_top; ++i) {  // heap node i -> position i + 1
@@ -1013,7 +1038,7 @@ tahoe_status tahoe_forest_create(tahoe_forest **out, const tahoe_dense_node *nod
                 memcpy(&a.y, &in[l].thr, 4);
                 memcpy(&a.z, &in[rr].thr, 4);
                 a.w = pack(in[r]) | (pack(in[l]) << 10) | (pack(in[rr]) << 20);
-                const float *lv = &h_leaf[t * f->n_leaf + 4 * b];
+                const float *lv = &h_leaf[t * n_leaf + 4 * b];
                 memcpy(&v.x, &lv[0], 4);
                 memcpy(&v.y, &lv[1], 4);
                 memcpy(&v.z, &lv[2], 4);
@@ -1022,6 +1047,7 @@ tahoe_status tahoe_forest_create(tahoe_forest **out, const tahoe_dense_node *nod
                 h_blocks[(t * n_blocks + b) * 2 + 1] = v;
             }
         }
+        });
     }
 
     auto bail = [&](hipError_t e, const char *what) {

@@ -550,13 +550,15 @@ static tahoe_status build_group(tahoe_forest *f, const std::vector<InnerNode> &h
         if (!h_real[i] || std::isnan(h_inner[i].thr)) continue;
         tab[h_inner[i].meta & 0x7fffffffu].push_back(h_inner[i].thr);
     }
+    parallel_for((size_t)cols, 4, [&tab](size_t c_lo, size_t c_hi) {  // features are independent
+        for (size_t c = c_lo; c < c_hi; ++c) {
+            auto &v = tab[c];
+            std::sort(v.begin(), v.end());                       // float order; -0.0f and 0.0f compare equal
+            v.erase(std::unique(v.begin(), v.end()), v.end());   // ... and collapse into one entry
+        }
+    });
     int max_count = 0;
-    for (int c = 0; c < cols; ++c) {
-        auto &v = tab[c];
-        std::sort(v.begin(), v.end());                       // float order; -0.0f and 0.0f compare equal
-        v.erase(std::unique(v.begin(), v.end()), v.end());   // ... and collapse into one entry
-        max_count = std::max(max_count, (int)v.size());
-    }
+    for (int c = 0; c < cols; ++c) max_count = std::max(max_count, (int)tab[c].size());
     if (max_count > kQMaxTable) {
         *too_many = max_count;
         return TAHOE_OK;
@@ -584,7 +586,8 @@ static tahoe_status build_group(tahoe_forest *f, const std::vector<InnerNode> &h
     std::vector<uint32_t> h_top(Tg * top_stride, 0u);
     std::vector<uint4> h_blocks(Tg * n_blocks * 2);
     std::vector<uint32_t> h_qinner(q->have_mid ? Tg * n_inner : 0);
-    for (size_t t = 0; t < Tg; ++t) {
+    parallel_for(Tg, 8, [&](size_t t_lo, size_t t_hi) {  // trees are independent; `encode` only reads
+    for (size_t t = t_lo; t < t_hi; ++t) {
         const InnerNode *in = &h_inner[(lo + t) * n_inner];
         const unsigned char *re = &h_real[(lo + t) * n_inner];
         for (size_t i = 0; i + 1 < top_n; ++i) h_top[t * top_stride + i + 1] = encode(in[i], re[i] != 0);
@@ -606,6 +609,7 @@ static tahoe_status build_group(tahoe_forest *f, const std::vector<InnerNode> &h
             h_blocks[(t * n_blocks + b) * 2 + 1] = v;
         }
     }
+    });
     {
         const tahoe_status qs = quantize_build_tables(f, tab, g);
         if (qs != TAHOE_OK) return qs;
