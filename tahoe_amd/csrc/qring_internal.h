@@ -45,7 +45,7 @@ struct tahoe_qstate {
     std::vector<tahoe_qgroup> groups;
     uint16_t *xq = nullptr;       // workspace: quantised tiles (re-used by every group)
     size_t xq_rows = 0;           // rows the workspace holds
-    uint32_t *chunk_flags = nullptr;  // workspace: per kQuantRowsPerBlock rows, "a missing value was seen"
+    uint32_t *chunk_flags = nullptr;  // workspace: per 2^cshift rows (the rows of one quantise workgroup), "a missing value was seen"
     size_t n_chunk_flags = 0;
 };
 namespace tahoe {

@@ -11,7 +11,7 @@
 namespace tahoe {
 
 // ------------------------------------------------------------------------------------------------
-// (1) float32 rows -> u16 codes.  One workgroup = F adjacent features x kQuantRowsPerBlock rows, the F
+// (1) float32 rows -> u16 codes.  One workgroup = F adjacent features x 2^cshift rows (quantize_launch), the F
 // search trees in LDS (stride `tab_stride` floats).  A thread reads the F values of a row with one
 // F*4-byte load: the row-major input is fetched in 64-byte lines of 16 features, and a workgroup uses
 // F*4 bytes of each line it pulls through L2 -> L1, so F = 2 halves and F = 4 quarters that traffic
@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(kQuantThreads) quantize_kernel(const float *__
     if (__ballot(saw_missing) != 0 && (threadIdx.x & 63) == 0) atomicOr(&chunk_flags[chunk], 1u);
 }
 
-// Pair form used when num_cols is even: one workgroup = features (f0, f0+1) x kQuantRowsPerBlock rows, float2
+// Pair form used when num_cols is even: one workgroup = features (f0, f0+1) x 2^cshift rows, float2
 // loads.  When both search trees fit the LDS budget they are resident together (one pass); a pair with an
 // oversized tree is done in two passes with one tree resident at a time, so a few large features do not
 // force the whole launch down to one feature per workgroup.
