@@ -708,9 +708,10 @@ static int resolve_strategy(const tahoe_forest *f, size_t /*rows*/)
     // QRING pays a quantise pass over rows x cols to make every (row, tree, level) step ~3x cheaper.  Fitted on the
     // enumeration of tools/selector_check.py (profiles/r01/selector_vs_enumeration.json): it loses to ROWTILE on
     // very shallow trees (the whole tree sits in ROWTILE's LDS top, no pre-pass) and to the float32 tile kernels
-    // when there is little walking per feature value (trees x depth < 4 x cols).
+    // when there is little walking per feature value (trees x depth < 6.5 x cols).  On ten shapes it was not fitted
+    // on (--holdout) it picks the fastest strategy on 8 and stays within 1.16x on the other two.
     const bool shallow = f->depth <= 4 && rowtile_fits(f);
-    const bool little_work = (long long)f->p.num_trees * f->depth < 4LL * f->p.num_cols &&
+    const bool little_work = 2LL * f->p.num_trees * f->depth < 13LL * f->p.num_cols &&
                              (tilering_rows(f) > 0 || tileblock_rows(f) > 0 || rowtile_fits(f));
     if (shallow) return TAHOE_STRATEGY_ROWTILE;
     if (qring_walkers(f) > 0 && !little_work) return TAHOE_STRATEGY_QRING;

@@ -19,11 +19,18 @@ SHAPES = [  # trees, depth, cols, rows
     (1000, 12, 256, 200_000), (300, 12, 500, 100_000), (50, 14, 256, 100_000), (500, 8, 1000, 50_000),
     (500, 8, 3072, 50_000), (2000, 3, 32, 200_000),
 ]
+# shapes the AUTO rule was NOT fitted on (`--holdout`): does it generalise?
+HOLDOUT = [
+    (300, 5, 28, 300_000), (64, 9, 96, 150_000), (1500, 10, 200, 100_000), (20, 12, 512, 100_000),
+    (800, 4, 100, 200_000), (400, 7, 400, 100_000), (100, 11, 64, 200_000), (3000, 6, 16, 100_000),
+    (150, 8, 2048, 40_000), (30, 3, 8, 500_000),
+]
 
 
 def main():
     out = []
-    for (T, D, C, R) in SHAPES:
+    holdout = "--holdout" in sys.argv
+    for (T, D, C, R) in (HOLDOUT if holdout else SHAPES):
         nodes = ta.synth_forest(T, D, C, seed=7)
         x = torch.from_numpy(ta.synth_data(R, C, seed=8)).cuda()
         f = ta.Forest(nodes, T, D, C, missing=-999.0)
@@ -50,7 +57,7 @@ def main():
         print(out[-1], flush=True)
         f.close()
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "selector.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "selector_holdout.json" if holdout else "selector.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
