@@ -65,15 +65,31 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
+    # TAHOE_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks share devices,
+    # collectives go through host memory); the numbers of such a run mean nothing, the code path is the same.
+    backend = os.environ.get("TAHOE_BENCH_BACKEND", "nccl")
+    device_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(device_index)
     dist = None
     if world > 1:
+        import datetime
+
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        import datetime
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index), timeout=datetime.timedelta(seconds=300))
+        else:
+            dist.init_process_group(backend, timeout=datetime.timedelta(seconds=300))
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=300))
+    def all_reduce(t, op=None):
+        kw = {} if op is None else {"op": op}
+        if backend == "nccl":
+            dist.all_reduce(t, **kw)  # RCCL over xGMI
+        else:
+            host = t.cpu()
+            dist.all_reduce(host, **kw)
+            t.copy_(host)
 
     T, D, C, R = args.trees, args.depth, args.cols, args.rows
     nodes = ta.synth_forest(T, D, C, seed=42)
@@ -95,7 +111,7 @@ def main():
         if world > 1 and args.shard == "trees":
             # tahoe_amd/sharding.py, TreeShardedForest.predict: partial sums, one all-reduce, transform
             forest.predict_raw(x, preds, stream=stream)
-            dist.all_reduce(preds)  # RCCL over xGMI: 4 B/row
+            all_reduce(preds)  # 4 B/row
             ta.capi.transform_preds(preds, 0, T, 0.0, 0.0, stream=stream)
         else:
             forest.predict(x, preds, stream=stream)
@@ -120,7 +136,7 @@ def main():
     forest.set_profiling(0)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     ms_per_step = dt / args.steps * 1e3
@@ -175,7 +191,7 @@ def main():
             def step4():
                 f4.predict_raw(x4, p4, stream=stream)
                 if world > 1:
-                    dist.all_reduce(p4)
+                    all_reduce(p4)
                 ta.capi.transform_preds(p4, 0, T4, 0.0, 0.0, stream=stream)
 
             k4, w4 = max(3, min(args.steps, 10)), 2
@@ -189,7 +205,7 @@ def main():
             t4 = time.perf_counter() - t4
             if world > 1:
                 tt = torch.tensor([t4], dtype=torch.float64, device="cuda")
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                all_reduce(tt, op=dist.ReduceOp.MAX)
                 t4 = float(tt.item())
             tree_leg = {"workload": f"K4: {T4} trees depth {D}, {C} features, {R} rows; trees split across {world} GPU(s), "
                                     f"one all-reduce of {4 * R} B per batch", "scaling": "strong",
