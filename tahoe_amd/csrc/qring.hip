@@ -659,7 +659,7 @@ tahoe_status qring_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner,
             if (h_real[i] && !std::isnan(h_inner[i].thr)) ++per_feature[h_inner[i].meta & 0x7fffffffu];
         const size_t most = *std::max_element(per_feature.begin(), per_feature.end());
         if (most > (size_t)kQMaxTable + kQMaxTable / 2)
-            gsize = std::max<size_t>(1, (size_t)((double)T * kQMaxTable / (double)most));
+            gsize = std::max<size_t>(1, (size_t)((double)T * kQMaxTable / (double)most * 0.98));  // the busiest feature varies a little from group to group
     }
     while (lo < T) {
         size_t hi = std::min(T, lo + gsize);
