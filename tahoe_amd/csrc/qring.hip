@@ -650,37 +650,47 @@ tahoe_status qring_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner,
         q->narrow = cols <= 256 && qring_walkers(f) == 15 && qring_lds_tile(f) && !(e && atoi(e) == 0);
     }
     // ---- cut the forest into tree groups whose features each see <= kQMaxTable distinct thresholds ----
-    size_t lo = 0, gsize = T;
+    // G groups of (nearly) equal size, G as small as the busiest feature allows.  First guess from the node counts per
+    // feature (an upper bound of its distinct thresholds), then G grows until every group fits; trees that differ
+    // wildly in size make that loop longer, never wrong.
+    size_t G = 1;
     {
-        // first guess from the node counts per feature (an upper bound of the distinct thresholds): saves building
-        // and throwing away the tables of a forest that obviously needs several groups (K4: 8 s -> 4 s of create)
         std::vector<size_t> per_feature((size_t)cols, 0);
         for (size_t i = 0; i < T * f->n_inner; ++i)
             if (h_real[i] && !std::isnan(h_inner[i].thr)) ++per_feature[h_inner[i].meta & 0x7fffffffu];
         const size_t most = *std::max_element(per_feature.begin(), per_feature.end());
-        if (most > (size_t)kQMaxTable + kQMaxTable / 2)
-            gsize = std::max<size_t>(1, (size_t)((double)T * kQMaxTable / (double)most * 0.98));  // the busiest feature varies a little from group to group
+        if (most > (size_t)kQMaxTable + kQMaxTable / 2) G = (most + kQMaxTable - 1) / kQMaxTable;  // below 1.5x: try one group first
     }
-    while (lo < T) {
-        size_t hi = std::min(T, lo + gsize);
-        tahoe_qgroup g;
-        for (;;) {
+    const size_t bytes_before = f->device_bytes;
+    for (;;) {
+        if (G > T) G = T;
+        bool fits = true;
+        int worst = 0;
+        for (size_t k = 0; k < G && fits; ++k) {
+            const size_t lo = T * k / G, hi = T * (k + 1) / G;
+            tahoe_qgroup g;
             int too_many = 0;
             const tahoe_status s = build_group(f, h_inner, h_real, h_leaf, lo, hi, g, &too_many);
             if (s != TAHOE_OK) {
                 free_group(g);
                 return s;  // create() destroys the handle, which frees the finished groups
             }
-            if (too_many == 0) break;
-            if (hi - lo == 1) {  // a single tree exceeds the limit: the strategy is unavailable
-                qring_destroy(f);
-                return TAHOE_OK;
+            if (too_many) {
+                fits = false;
+                worst = too_many;
+            } else {
+                q->groups.push_back(g);
             }
-            gsize = std::max<size_t>(1, (size_t)((double)(hi - lo) * kQMaxTable / too_many * 0.9));
-            hi = lo + gsize;
         }
-        q->groups.push_back(g);
-        lo = hi;
+        if (fits) break;
+        for (tahoe_qgroup &g : q->groups) free_group(g);
+        q->groups.clear();
+        f->device_bytes = bytes_before;
+        if (G == T) {  // a single tree exceeds the limit: the strategy is unavailable
+            qring_destroy(f);
+            return TAHOE_OK;
+        }
+        G = std::max(G + 1, (size_t)((double)G * worst / kQMaxTable + 0.999));
     }
     // kernels that need more than 64 KiB of dynamic LDS
     hipError_t e;
