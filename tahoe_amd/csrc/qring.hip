@@ -294,7 +294,10 @@ __global__ void __launch_bounds__(16 * 64)
     constexpr int NT = (NWALK + 1) * 64;
     constexpr int TPW = 64 / RT;                       // trees a walker wave walks at once
     constexpr int RE = kWideRingBytes / (RT * 4);      // ring entries (trees): >= two rounds of NWALK * TPW
-    constexpr int NBATCH = RE / 2;                     // trees the consumer takes per poll (<= 64)
+#ifndef TAHOE_WIDE_BATCH
+#define TAHOE_WIDE_BATCH 64  // K2 (four trees per wave): 64 -> 1.07 ms, 16 -> 1.16, 8 -> 1.44
+#endif
+    constexpr int NBATCH = RE / 2 < TAHOE_WIDE_BATCH ? RE / 2 : TAHOE_WIDE_BATCH;  // trees the consumer takes per poll (<= 64)
     constexpr int CSHIFT = RT == 64 ? 7 : RT == 32 ? 6 : 5;  // log2 of a feature column's bytes
     static_assert(NBATCH <= 64 && RE >= 2 * NWALK * TPW, "ring too small");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

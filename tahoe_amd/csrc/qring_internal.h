@@ -52,8 +52,16 @@ namespace tahoe {
 
 
 constexpr int kQRows = 128;                 // rows per tile
-constexpr int kQRing = 16;                  // ring entries (trees)
-constexpr int kQBatch = 8;                  // trees the consumer takes per poll
+// Ring depth and consumer batch, tuned on K3 (tools/ablate_walk.sh style builds): 16/8 4.20 ms, 16/4 4.11, 24/4 4.08,
+// 32/4 4.14, 24/6 4.10, 24/3 4.28; a batch of 2 or 1 makes the consumer's polling the bottleneck (4.9 / 6.6 ms).
+#ifndef TAHOE_QRING_RING
+#define TAHOE_QRING_RING 24
+#endif
+#ifndef TAHOE_QRING_BATCH
+#define TAHOE_QRING_BATCH 4
+#endif
+constexpr int kQRing = TAHOE_QRING_RING;    // ring entries (trees)
+constexpr int kQBatch = TAHOE_QRING_BATCH;  // trees the consumer takes per poll
 constexpr int kQSpinLimit = 1 << 22;
 constexpr int kQSlotBytes = 4096;            // LDS per walker: a 10-level top (2^10 u32)
 constexpr int kQMaxTable = 32767;

@@ -120,7 +120,10 @@ __global__ void __launch_bounds__(kBlock) sparse_kernel(const tahoe_sparse_node 
 // cannot be blocked; every spin is bounded and raises the error flag.
 constexpr int kSTop = 512;    // nodes per slot (8 B each)
 constexpr int kSRing = 32;    // ring entries (trees)
-constexpr int kSBatch = 16;   // trees the consumer takes per poll
+#ifndef TAHOE_SPARSE_BATCH
+#define TAHOE_SPARSE_BATCH 4  // K5: 16 -> 5.34 ms, 8 -> 5.19, 4 -> 5.15
+#endif
+constexpr int kSBatch = TAHOE_SPARSE_BATCH;   // trees the consumer takes per poll
 constexpr int kSSpinLimit = 1 << 22;
 template <int NW, bool WRITE_LEAF>
 __global__ void __launch_bounds__(NW * 64) sparse_top_kernel(const uint2 *__restrict__ cnodes, const int32_t *__restrict__ ctrees,
