@@ -575,7 +575,7 @@ tahoe_status quantize_launch(tahoe_forest *f, const tahoe_qgroup &g, const float
     tahoe_qstate *q = f->q;
     const bool pair_ok = g.pair_lds_floats > 0 && (reinterpret_cast<uintptr_t>(data) % 8) == 0;  // float2 loads
     const bool multi_ok = g.multi_q > 0 && (reinterpret_cast<uintptr_t>(data) % 16) == 0;  // float4 loads
-    // Rows per quantise workgroup (2^cshift): as many as 32768 so that staging the tables is amortised, fewer when
+    // Rows per quantise workgroup (2^cshift): as many as 65536 so that staging the tables is amortised, fewer when
     // that would leave the chip short of workgroups (few columns or rows), never so few that the tables outweigh
     // the rows a workgroup converts.
     const int feats = multi_ok ? 4 * g.multi_q : pair_ok ? 2 : 1;
