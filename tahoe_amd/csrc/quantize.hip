@@ -133,15 +133,25 @@ __global__ void __launch_bounds__(kQuantPairThreads)
         if (do1)
             for (int i = threadIdx.x; i < size1; i += blockDim.x) tab[(together ? size0 : 0) + i] = tables[base1 + i];
         __syncthreads();
+        float2 nx[U];  // next iteration's rows, loaded one iteration ahead (see quantize_bucket_pair_kernel)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t r = min(r0 + threadIdx.x + (size_t)u * blockDim.x, r1 - 1);
+            nx[u] = *reinterpret_cast<const float2 *>(data + r * (size_t)cols + f0);
+        }
         for (size_t rb = r0 + threadIdx.x; rb < r1; rb += (size_t)blockDim.x * U) {
             float2 xv[U];
             int c0[U], c1[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const size_t r = min(rb + (size_t)u * blockDim.x, r1 - 1);  // clamped: in bounds, result unused
-                xv[u] = *reinterpret_cast<const float2 *>(data + r * (size_t)cols + f0);
+                xv[u] = nx[u];
                 c0[u] = 1;
                 c1[u] = 1;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const size_t r = min(rb + (size_t)(U + u) * blockDim.x, r1 - 1);  // clamped: in bounds, result unused
+                nx[u] = *reinterpret_cast<const float2 *>(data + r * (size_t)cols + f0);
             }
             // descend both trees: k <- 2k + (tab[k] <= x); k - 2^p = #{thresholds <= x} (NaN x -> 0)
             if (do0)
@@ -236,13 +246,23 @@ __global__ void __launch_bounds__(kQuantPairThreads)
     const size_t r1 = min(rows, r0 + ((size_t)1 << cshift));
     constexpr int U = 4;
     bool saw_missing = false;
+    // the rows of the next iterations are loaded before the current ones are converted: the loads (a new cache line
+    // each, HBM latency) fly under the searching
+    float2 nx[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const size_t r = min(r0 + threadIdx.x + (size_t)u * blockDim.x, r1 - 1);
+        nx[u] = *reinterpret_cast<const float2 *>(data + r * (size_t)cols + f0);
+    }
     for (size_t rb = r0 + threadIdx.x; rb < r1; rb += (size_t)blockDim.x * U) {
         float2 xv[U];
         int c0[U], c1[U];
 #pragma unroll
+        for (int u = 0; u < U; ++u) xv[u] = nx[u];
+#pragma unroll
         for (int u = 0; u < U; ++u) {
-            const size_t r = min(rb + (size_t)u * blockDim.x, r1 - 1);  // clamped: in bounds, result unused
-            xv[u] = *reinterpret_cast<const float2 *>(data + r * (size_t)cols + f0);
+            const size_t r = min(rb + (size_t)(U + u) * blockDim.x, r1 - 1);  // clamped: in bounds, result unused
+            nx[u] = *reinterpret_cast<const float2 *>(data + r * (size_t)cols + f0);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {  // positions are kept in bytes: one add forms the probe address
@@ -327,12 +347,20 @@ __global__ void __launch_bounds__(kQuantPairThreads)
     const size_t r0 = chunk << cshift;
     const size_t r1 = min(rows, r0 + ((size_t)1 << cshift));
     bool saw_missing = false;
+    float4 nx[U];  // next iteration's rows, loaded one iteration ahead (see quantize_bucket_pair_kernel)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const size_t r = min(r0 + rsub + (size_t)u * RPI, r1 - 1);
+        nx[u] = *reinterpret_cast<const float4 *>(data + r * (size_t)cols + fq);
+    }
     for (size_t rb = r0 + rsub; rb < r1; rb += (size_t)RPI * U) {
         float4 xv[U];
 #pragma unroll
+        for (int u = 0; u < U; ++u) xv[u] = nx[u];
+#pragma unroll
         for (int u = 0; u < U; ++u) {
-            const size_t r = min(rb + (size_t)u * RPI, r1 - 1);  // clamped: in bounds, result unused
-            xv[u] = *reinterpret_cast<const float4 *>(data + r * (size_t)cols + fq);
+            const size_t r = min(rb + (size_t)(U + u) * RPI, r1 - 1);  // clamped: in bounds, result unused
+            nx[u] = *reinterpret_cast<const float4 *>(data + r * (size_t)cols + fq);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
