@@ -109,9 +109,15 @@ enum {
                                     leaf values in tree order through an LDS ring */
     TAHOE_STRATEGY_QRING = 5     /* TILERING on rank-quantised data: features and thresholds become
                                     exact 16-bit ranks (a per-predict quantise pass), 128-row u16 tile,
-                                    4-byte nodes, up to 15 walker waves x 2 chains; available when every
-                                    feature has <= 32767 distinct thresholds */
+                                    4-byte nodes, up to 15 walker waves x 2 chains; rows too wide for that
+                                    tile use 64- / 32- / 16-row tiles with several trees per wave; forests
+                                    with more than 32767 distinct thresholds on a feature are walked in
+                                    groups of consecutive trees with chained float32 sums (still the one
+                                    sequential sum); unavailable only if a single tree exceeds that */
 };
+/* On a sparse handle (tahoe_sparse_forest_create): DIRECT = nodes and features from global memory,
+ * ROWTILE = 64-row float32 tile in LDS, TILEBLOCK = tile + the first 512 nodes of each tree (breadth-first)
+ * in LDS, walker waves + ordered ring consumer (AUTO's choice when trees have <= 65536 nodes). */
 
 typedef struct tahoe_forest tahoe_forest; /* opaque */
 
