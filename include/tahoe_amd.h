@@ -167,6 +167,14 @@ tahoe_status tahoe_forest_predict(tahoe_forest *f, float *preds_dev, const float
 tahoe_status tahoe_forest_predict_raw(tahoe_forest *f, float *sums_dev, const float *data_dev, size_t rows,
                                       void *stream);
 
+/* Chained tree shards ("sum-order caveat"): sums_dev[rows] holds, on entry, the float32 sums of the trees
+ * that come BEFORE this forest's trees in the whole ensemble; on return, those sums continued through this forest's
+ * trees in tree order.  Shard k called on shard k-1's output therefore reproduces the single sequential float32 sum of
+ * predict_on_cpu (BaseTahoeTest.h:462-466) bit for bit, which an all-reduce of per-shard totals cannot.  Every
+ * strategy supports it (the kernels start their per-row accumulator from sums_dev[row] instead of 0.0f). */
+tahoe_status tahoe_forest_predict_accumulate(tahoe_forest *f, float *sums_dev, const float *data_dev, size_t rows,
+                                             void *stream);
+
 /* leaf_dev[row * num_trees + tree] <- index of the leaf the row ends in, in the tree's original heap
  * numbering (final `curr` of infer_one_tree, BaseTahoeTest.h:441-455).  sums_dev may be NULL. */
 tahoe_status tahoe_forest_predict_leaf_idx(tahoe_forest *f, uint32_t *leaf_dev, float *sums_dev,
@@ -276,6 +284,11 @@ tahoe_status tahoe_device_count(int *count);
 tahoe_status tahoe_device_set(int device);
 tahoe_status tahoe_device_alloc(void **ptr, size_t bytes, int set_zero);   /* allocate(), cuda_base.h:28-32 */
 tahoe_status tahoe_device_free(void *ptr);
+tahoe_status tahoe_device_memset(void *ptr_dev, int value, size_t bytes, void *stream);
+/* float32 <-> float64 on the device: tree shards that exchange their per-row partial sums by an all-reduce do it
+ * on float64 copies (8 bytes per row), so that combining the partials adds no float32 rounding of its own. */
+tahoe_status tahoe_widen_f32_to_f64(double *dst_dev, const float *src_dev, size_t n, void *stream);
+tahoe_status tahoe_narrow_f64_to_f32(float *dst_dev, const double *src_dev, size_t n, void *stream);
 tahoe_status tahoe_copy_to_device(void *dst_dev, const void *src_host, size_t bytes, void *stream);
 tahoe_status tahoe_copy_to_host(void *dst_host, const void *src_dev, size_t bytes, void *stream);
 tahoe_status tahoe_stream_create(void **stream);

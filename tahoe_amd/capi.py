@@ -117,6 +117,7 @@ _PROTOS = {
     "tahoe_synth_sparse_forest": (_i, [_vp, _vp, C.POINTER(_sz), _i, _i, _i, _i, _f, _i, C.c_uint64]),
     "tahoe_forest_predict": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "tahoe_forest_predict_raw": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "tahoe_forest_predict_accumulate": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "tahoe_forest_predict_leaf_idx": (_i, [_vp, _vp, _vp, _vp, _sz, _vp]),
     "tahoe_transform_preds": (_i, [_vp, _sz, _i, _i, _f, _f, _vp]),
     "tahoe_forest_set_strategy": (_i, [_vp, _i]),
@@ -147,6 +148,9 @@ _PROTOS = {
     "tahoe_device_set": (_i, [_i]),
     "tahoe_device_alloc": (_i, [C.POINTER(_vp), _sz, _i]),
     "tahoe_device_free": (_i, [_vp]),
+    "tahoe_device_memset": (_i, [_vp, _i, _sz, _vp]),
+    "tahoe_widen_f32_to_f64": (_i, [_vp, _vp, _sz, _vp]),
+    "tahoe_narrow_f64_to_f32": (_i, [_vp, _vp, _sz, _vp]),
     "tahoe_copy_to_device": (_i, [_vp, _vp, _sz, _vp]),
     "tahoe_copy_to_host": (_i, [_vp, _vp, _sz, _vp]),
     "tahoe_stream_create": (_i, [C.POINTER(_vp)]),
@@ -354,6 +358,16 @@ class Forest:
                "tahoe_forest_predict_raw")
         return sums
 
+    def predict_accumulate(self, data, sums, stream=None):
+        """Continues the running float32 sums in `sums` (the trees before this forest) through this forest's trees,
+        in place (tahoe_forest_predict_accumulate): the step of a chained, bit-exact tree-sharded predict."""
+        self._check_data(data)
+        assert sums.is_cuda and sums.is_contiguous() and sums.dtype.is_floating_point and sums.element_size() == 4
+        assert sums.numel() == data.shape[0]
+        _check(lib.tahoe_forest_predict_accumulate(self._h, _ptr(sums), _ptr(data), data.shape[0], _stream(stream)),
+               "tahoe_forest_predict_accumulate")
+        return sums
+
     def predict_leaf_idx(self, data, want_sums: bool = True, stream=None):
         import torch
 
@@ -381,6 +395,9 @@ class Forest:
             raise ValueError(f"data must be C-contiguous float32 [rows, {self.num_cols}]")
         if preds is None:
             preds = np.empty(data.shape[0], dtype=np.float32)
+        if (not isinstance(preds, np.ndarray) or preds.dtype != np.float32 or preds.shape != (data.shape[0],)
+                or not preds.flags.c_contiguous or not preds.flags.writeable):
+            raise ValueError(f"preds must be a writeable C-contiguous float32 array of shape ({data.shape[0]},)")
         _check(lib.tahoe_forest_predict_host(self._h, preds.ctypes.data, data.ctypes.data, data.shape[0], chunk_rows),
                "tahoe_forest_predict_host")
         return preds

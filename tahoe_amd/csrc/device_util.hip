@@ -3,6 +3,8 @@
 // updateHost / copy) and compare_GPU (cuda_base.h:98-111) of the reference.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace tahoe {
@@ -21,6 +23,16 @@ __global__ void compare_kernel(const float *__restrict__ a, const float *__restr
     // wave64 reduction, then one atomic per wave
     for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(bad, local);
+}
+
+__global__ void widen_kernel(double *__restrict__ dst, const float *__restrict__ src, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = (double)src[i];
+}
+
+__global__ void narrow_kernel(float *__restrict__ dst, const double *__restrict__ src, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = (float)src[i];
 }
 
 }  // namespace tahoe
@@ -73,6 +85,33 @@ tahoe_status tahoe_host_free(void *ptr)
 tahoe_status tahoe_device_free(void *ptr)
 {
     if (ptr) TAHOE_HIP_TRY(hipFree(ptr));
+    return TAHOE_OK;
+}
+
+tahoe_status tahoe_device_memset(void *ptr_dev, int value, size_t bytes, void *stream)
+{
+    if (bytes && !ptr_dev) return fail(TAHOE_ERR_INVALID_ARG, "null argument");
+    if (bytes) TAHOE_HIP_TRY(hipMemsetAsync(ptr_dev, value, bytes, (hipStream_t)stream));
+    return TAHOE_OK;
+}
+
+tahoe_status tahoe_widen_f32_to_f64(double *dst_dev, const float *src_dev, size_t n, void *stream)
+{
+    if (n && (!dst_dev || !src_dev)) return fail(TAHOE_ERR_INVALID_ARG, "null argument");
+    if (n == 0) return TAHOE_OK;
+    const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(widen_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dst_dev, src_dev, n);
+    TAHOE_HIP_TRY(hipGetLastError());
+    return TAHOE_OK;
+}
+
+tahoe_status tahoe_narrow_f64_to_f32(float *dst_dev, const double *src_dev, size_t n, void *stream)
+{
+    if (n && (!dst_dev || !src_dev)) return fail(TAHOE_ERR_INVALID_ARG, "null argument");
+    if (n == 0) return TAHOE_OK;
+    const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(narrow_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dst_dev, src_dev, n);
+    TAHOE_HIP_TRY(hipGetLastError());
     return TAHOE_OK;
 }
 

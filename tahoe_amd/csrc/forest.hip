@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(kBlock) direct_kernel(const InnerNode *__restr
                                                         const float *__restrict__ leaf_val,
                                                         const uint32_t *__restrict__ leaf_orig,
                                                         const float *__restrict__ data, float *__restrict__ sums,
-                                                        uint32_t *__restrict__ leaf_out, size_t rows, int cols,
+                                                        uint32_t *__restrict__ leaf_out, const float *sums_in, size_t rows, int cols,
                                                         int num_trees, int depth, float missing)
 {
     const size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x;
@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(kBlock) direct_kernel(const InnerNode *__restr
     const float *x = data + row * (size_t)cols;
     const size_t n_inner = ((size_t)1 << depth) - 1;
     const size_t n_leaf = (size_t)1 << depth;
-    float sum = 0.0f;
+    float sum = sums_in ? sums_in[row] : 0.0f;  // continues a running sum (tree shards chained in order)
     for (int t = 0; t < num_trees; ++t) {
         const InnerNode *tree = inner + (size_t)t * n_inner;
         uint32_t idx = 0;
@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(kBlock) rowtile_kernel(const InnerNode *__rest
                                                          const float *__restrict__ leaf_val,
                                                          const uint32_t *__restrict__ leaf_orig,
                                                          const float *__restrict__ data, float *__restrict__ sums,
-                                                         uint32_t *__restrict__ leaf_out, size_t rows, int cols,
+                                                         uint32_t *__restrict__ leaf_out, const float *sums_in, size_t rows, int cols,
                                                          int num_trees, int depth, int lds_levels, float missing,
                                                          int vec4_ok)
 {
@@ -153,6 +153,7 @@ __global__ void __launch_bounds__(kBlock) rowtile_kernel(const InnerNode *__rest
     __syncthreads();  // tile and every wave's first slot are in LDS
 
     float sum = 0.0f;  // meaningful in lanes 0..15: row 16*wave + lane of the tile
+    if (sums_in && lane < 16 && row0 + 16 * wave + lane < rows) sum = sums_in[row0 + 16 * wave + lane];
     const int rounds = (num_trees + kWaves - 1) / kWaves;
     for (int r = 0; r < rounds; ++r) {
         const int t = r * kWaves + wave;
@@ -211,7 +212,7 @@ __global__ void __launch_bounds__(kSlots *ROWS)
     tileblock_kernel(const unsigned char *__restrict__ top, const uint4 *__restrict__ blocks,
                      const InnerNode *__restrict__ inner, const uint32_t *__restrict__ leaf_orig,
                      const float *__restrict__ data, float *__restrict__ sums, uint32_t *__restrict__ leaf_out,
-                     size_t rows, int cols, int num_trees, int depth, int top_levels, int top_stride, float missing,
+                     const float *sums_in, size_t rows, int cols, int num_trees, int depth, int top_levels, int top_stride, float missing,
                      int vec4_ok)
 {
     constexpr int RG = ROWS / 64;            // waves per slot (row groups)
@@ -300,6 +301,7 @@ __global__ void __launch_bounds__(kSlots *ROWS)
     const uint32_t n_blocks = 1u << (depth - 2);
     const uint32_t first_block_node = n_blocks - 1;  // heap index of the first node of level depth-2
     float sum = 0.0f;                                // lanes 0..OWN-1: row OWN*wave + lane of the tile
+    if (sums_in && lane < OWN && row0 + OWN * wave + lane < rows) sum = sums_in[row0 + OWN * wave + lane];
     const int rounds = (num_trees + kSlots - 1) / kSlots;
     for (int r = 0; r < rounds; ++r) {
         const int t = r * kSlots + slot_id;
@@ -400,7 +402,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
     tilering_kernel(const unsigned char *__restrict__ top, const uint4 *__restrict__ blocks,
                     const InnerNode *__restrict__ inner, const uint32_t *__restrict__ leaf_orig,
                     const float *__restrict__ data, float *__restrict__ sums, uint32_t *__restrict__ leaf_out,
-                    size_t rows, int cols, int num_trees, int depth, int top_levels, int top_stride, float missing,
+                    const float *sums_in, size_t rows, int cols, int num_trees, int depth, int top_levels, int top_stride, float missing,
                     int vec4_ok, int *__restrict__ error_flag)
 {
     constexpr int K = ROWS / 64;
@@ -451,7 +453,10 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
         __syncthreads();
         float sum[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) sum[k] = 0.0f;
+        for (int k = 0; k < K; ++k) {
+            const size_t irow = row0 + k * 64 + lane;
+            sum[k] = (sums_in && irow < rows) ? sums_in[irow] : 0.0f;
+        }
         bool dead = false;
         for (int t0 = 0; t0 < num_trees && !dead; t0 += BATCH) {
             const int nb = min(BATCH, num_trees - t0);
@@ -667,10 +672,8 @@ static long long tileblock_lds_bytes(const tahoe_forest *f, int tile_rows)
 static int tileblock_rows(const tahoe_forest *f)
 {
     if (!f->has_blocks || f->p.num_cols < 1) return 0;
-    if (const char *e = getenv("TAHOE_TILE_ROWS")) {  // tuning knob for experiments
-        const int r = atoi(e);
+    if (const int r = f->knob_tile_rows)  // TAHOE_TILE_ROWS, read at create
         if ((r == 64 || r == 128) && tileblock_lds_bytes(f, r) <= f->lds_limit) return r;
-    }
     if (tileblock_lds_bytes(f, 128) <= f->lds_limit) return 128;
     if (tileblock_lds_bytes(f, 64) <= f->lds_limit) return 64;
     return 0;
@@ -688,10 +691,8 @@ static long long tilering_lds_bytes(const tahoe_forest *f, int tile_rows)
 static int tilering_rows(const tahoe_forest *f)
 {
     if (!f->has_blocks || f->p.num_cols < 1) return 0;
-    if (const char *e = getenv("TAHOE_TILE_ROWS")) {  // tuning knob for experiments
-        const int r = atoi(e);
+    if (const int r = f->knob_tile_rows)  // TAHOE_TILE_ROWS, read at create
         if ((r == 64 || r == 128) && tilering_lds_bytes(f, r) <= f->lds_limit) return r;
-    }
     if (tilering_lds_bytes(f, 64) <= f->lds_limit) return 64;
     return 0;
 }
@@ -721,7 +722,7 @@ static int resolve_strategy(const tahoe_forest *f, size_t /*rows*/)
 }
 
 template <int ROWS>
-static void launch_tileblock(tahoe_forest *f, float *sums, uint32_t *leaf_out, const float *data, size_t rows,
+static void launch_tileblock(tahoe_forest *f, float *sums, uint32_t *leaf_out, const float *sums_in, const float *data, size_t rows,
                              hipStream_t stream, int vec4_ok)
 {
     const unsigned grid = (unsigned)((rows + ROWS - 1) / ROWS);
@@ -729,16 +730,16 @@ static void launch_tileblock(tahoe_forest *f, float *sums, uint32_t *leaf_out, c
     const int stride = top_stride_bytes(f->top_levels);
     if (leaf_out)
         hipLaunchKernelGGL((tileblock_kernel<ROWS, true>), dim3(grid), dim3(kSlots * ROWS), lds, stream, f->top,
-                           f->blocks, f->inner, f->leaf_orig, data, sums, leaf_out, rows, f->p.num_cols,
+                           f->blocks, f->inner, f->leaf_orig, data, sums, leaf_out, sums_in, rows, f->p.num_cols,
                            f->p.num_trees, f->depth, f->top_levels, stride, f->p.missing, vec4_ok);
     else
         hipLaunchKernelGGL((tileblock_kernel<ROWS, false>), dim3(grid), dim3(kSlots * ROWS), lds, stream, f->top,
-                           f->blocks, f->inner, f->leaf_orig, data, sums, leaf_out, rows, f->p.num_cols,
+                           f->blocks, f->inner, f->leaf_orig, data, sums, leaf_out, sums_in, rows, f->p.num_cols,
                            f->p.num_trees, f->depth, f->top_levels, stride, f->p.missing, vec4_ok);
 }
 
 template <int ROWS, int NWALK>
-static void launch_tilering(tahoe_forest *f, float *sums, uint32_t *leaf_out, const float *data, size_t rows,
+static void launch_tilering(tahoe_forest *f, float *sums, uint32_t *leaf_out, const float *sums_in, const float *data, size_t rows,
                             hipStream_t stream, int vec4_ok)
 {
     const unsigned grid = (unsigned)((rows + ROWS - 1) / ROWS);
@@ -746,11 +747,11 @@ static void launch_tilering(tahoe_forest *f, float *sums, uint32_t *leaf_out, co
     const int stride = top_stride_bytes(f->top_levels);
     if (leaf_out)
         hipLaunchKernelGGL((tilering_kernel<ROWS, NWALK, true>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream,
-                           f->top, f->blocks, f->inner, f->leaf_orig, data, sums, leaf_out, rows, f->p.num_cols,
+                           f->top, f->blocks, f->inner, f->leaf_orig, data, sums, leaf_out, sums_in, rows, f->p.num_cols,
                            f->p.num_trees, f->depth, f->top_levels, stride, f->p.missing, vec4_ok, f->error_flag);
     else
         hipLaunchKernelGGL((tilering_kernel<ROWS, NWALK, false>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream,
-                           f->top, f->blocks, f->inner, f->leaf_orig, data, sums, leaf_out, rows, f->p.num_cols,
+                           f->top, f->blocks, f->inner, f->leaf_orig, data, sums, leaf_out, sums_in, rows, f->p.num_cols,
                            f->p.num_trees, f->depth, f->top_levels, stride, f->p.missing, vec4_ok, f->error_flag);
 }
 
@@ -771,8 +772,10 @@ struct DeviceGuard {
     DeviceGuard &operator=(const DeviceGuard &) = delete;
 };
 
+// sums_in (optional, may be `sums` itself): running float32 sums of the trees BEFORE this forest -- every kernel then
+// continues that sum in tree order instead of starting from 0.0f (tahoe_forest_predict_accumulate).
 static tahoe_status launch_traversal(tahoe_forest *f, float *sums, uint32_t *leaf_out, const float *data,
-                                     size_t rows, hipStream_t stream)
+                                     size_t rows, hipStream_t stream, const float *sums_in = nullptr)
 {
     if (rows == 0) return TAHOE_OK;
     DeviceGuard on_device(f->device);
@@ -784,12 +787,15 @@ static tahoe_status launch_traversal(tahoe_forest *f, float *sums, uint32_t *lea
     const int vec4_ok = (f->p.num_cols % 4 == 0) && ((reinterpret_cast<uintptr_t>(data) & 15u) == 0);
     if (f->p.num_trees == 0) {
         // Nothing to walk: sums are zero (an empty j-loop in predict_on_cpu).
-        if (sums) TAHOE_HIP_TRY(hipMemsetAsync(sums, 0, rows * sizeof(float), stream));
+        if (sums && sums_in && sums != sums_in)
+            TAHOE_HIP_TRY(hipMemcpyAsync(sums, sums_in, rows * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        else if (sums && !sums_in)
+            TAHOE_HIP_TRY(hipMemsetAsync(sums, 0, rows * sizeof(float), stream));
     } else if (f->sp) {
-        const tahoe_status ss = sparse_launch(f, sums, leaf_out, data, rows, stream, strategy);
+        const tahoe_status ss = sparse_launch(f, sums, leaf_out, data, rows, stream, strategy, sums_in);
         if (ss != TAHOE_OK) return ss;
     } else if (strategy == TAHOE_STRATEGY_QRING) {
-        const tahoe_status qs = qring_launch(f, sums, leaf_out, data, rows, stream, timed ? f->ev_mid[f->prof_count] : nullptr);
+        const tahoe_status qs = qring_launch(f, sums, leaf_out, data, rows, stream, timed ? f->ev_mid[f->prof_count] : nullptr, sums_in);
         mid_recorded = timed;
         if (qs != TAHOE_OK) return qs;
     } else if (strategy == TAHOE_STRATEGY_TILERING) {
@@ -798,9 +804,9 @@ static tahoe_status launch_traversal(tahoe_forest *f, float *sums, uint32_t *lea
             return fail(TAHOE_ERR_UNSUPPORTED, "TILERING needs num_cols <= %d and a 64-row tile that fits %d B of LDS",
                         kBlockMaxCols, f->lds_limit);
         if (tr == 128)
-            launch_tilering<128, 4>(f, sums, leaf_out, data, rows, stream, vec4_ok);
+            launch_tilering<128, 4>(f, sums, leaf_out, sums_in, data, rows, stream, vec4_ok);
         else
-            launch_tilering<64, 8>(f, sums, leaf_out, data, rows, stream, vec4_ok);
+            launch_tilering<64, 8>(f, sums, leaf_out, sums_in, data, rows, stream, vec4_ok);
         TAHOE_HIP_TRY(hipGetLastError());
     } else if (strategy == TAHOE_STRATEGY_TILEBLOCK) {
         const int tr = tileblock_rows(f);
@@ -808,9 +814,9 @@ static tahoe_status launch_traversal(tahoe_forest *f, float *sums, uint32_t *lea
             return fail(TAHOE_ERR_UNSUPPORTED, "TILEBLOCK needs num_cols <= %d and a 64-row tile that fits %d B of LDS",
                         kBlockMaxCols, f->lds_limit);
         if (tr == 128)
-            launch_tileblock<128>(f, sums, leaf_out, data, rows, stream, vec4_ok);
+            launch_tileblock<128>(f, sums, leaf_out, sums_in, data, rows, stream, vec4_ok);
         else
-            launch_tileblock<64>(f, sums, leaf_out, data, rows, stream, vec4_ok);
+            launch_tileblock<64>(f, sums, leaf_out, sums_in, data, rows, stream, vec4_ok);
         TAHOE_HIP_TRY(hipGetLastError());
     } else if (strategy == TAHOE_STRATEGY_ROWTILE) {
         if (!rowtile_fits(f))
@@ -820,22 +826,22 @@ static tahoe_status launch_traversal(tahoe_forest *f, float *sums, uint32_t *lea
         const int lds = rowtile_lds_bytes(f->p.num_cols, f->lds_levels);
         if (leaf_out)
             hipLaunchKernelGGL(rowtile_kernel<true>, dim3((unsigned)grid), dim3(kBlock), lds, stream, f->inner,
-                               f->leaf_val, f->leaf_orig, data, sums, leaf_out, rows, f->p.num_cols,
+                               f->leaf_val, f->leaf_orig, data, sums, leaf_out, sums_in, rows, f->p.num_cols,
                                f->p.num_trees, f->depth, f->lds_levels, f->p.missing, vec4_ok);
         else
             hipLaunchKernelGGL(rowtile_kernel<false>, dim3((unsigned)grid), dim3(kBlock), lds, stream, f->inner,
-                               f->leaf_val, f->leaf_orig, data, sums, leaf_out, rows, f->p.num_cols,
+                               f->leaf_val, f->leaf_orig, data, sums, leaf_out, sums_in, rows, f->p.num_cols,
                                f->p.num_trees, f->depth, f->lds_levels, f->p.missing, vec4_ok);
         TAHOE_HIP_TRY(hipGetLastError());
     } else if (strategy == TAHOE_STRATEGY_DIRECT) {
         const size_t grid = (rows + kBlock - 1) / kBlock;
         if (leaf_out)
             hipLaunchKernelGGL(direct_kernel<true>, dim3((unsigned)grid), dim3(kBlock), 0, stream, f->inner,
-                               f->leaf_val, f->leaf_orig, data, sums, leaf_out, rows, f->p.num_cols,
+                               f->leaf_val, f->leaf_orig, data, sums, leaf_out, sums_in, rows, f->p.num_cols,
                                f->p.num_trees, f->depth, f->p.missing);
         else
             hipLaunchKernelGGL(direct_kernel<false>, dim3((unsigned)grid), dim3(kBlock), 0, stream, f->inner,
-                               f->leaf_val, f->leaf_orig, data, sums, leaf_out, rows, f->p.num_cols,
+                               f->leaf_val, f->leaf_orig, data, sums, leaf_out, sums_in, rows, f->p.num_cols,
                                f->p.num_trees, f->depth, f->p.missing);
         TAHOE_HIP_TRY(hipGetLastError());
     } else {
@@ -927,6 +933,8 @@ tahoe_status tahoe_forest_create(tahoe_forest **out, const tahoe_dense_node *nod
         f->lds_levels = std::max(0, std::min(f->lds_levels, atoi(e)));
         f->top_levels = std::max(0, std::min(f->top_levels, atoi(e)));
     }
+    if (const char *e = getenv("TAHOE_TILE_ROWS")) f->knob_tile_rows = atoi(e);
+    if (const char *e = getenv("TAHOE_QRING_WALKERS")) f->knob_qring_walkers = atoi(e);
     f->has_blocks = p->num_cols <= kBlockMaxCols;
 
     // ---- normalise: heap records of the perfect depth-De tree ----
@@ -1123,6 +1131,14 @@ tahoe_status tahoe_forest_predict_raw(tahoe_forest *f, float *sums_dev, const fl
     if (!f || (rows && (!sums_dev || !data_dev)))
         return fail(TAHOE_ERR_INVALID_ARG, "tahoe_forest_predict_raw: null argument");
     return launch_traversal(f, sums_dev, nullptr, data_dev, rows, (hipStream_t)stream);
+}
+
+tahoe_status tahoe_forest_predict_accumulate(tahoe_forest *f, float *sums_dev, const float *data_dev, size_t rows,
+                                             void *stream)
+{
+    if (!f || (rows && (!sums_dev || !data_dev)))
+        return fail(TAHOE_ERR_INVALID_ARG, "tahoe_forest_predict_accumulate: null argument");
+    return launch_traversal(f, sums_dev, nullptr, data_dev, rows, (hipStream_t)stream, sums_dev);
 }
 
 tahoe_status tahoe_forest_predict(tahoe_forest *f, float *preds_dev, const float *data_dev, size_t rows,

@@ -67,6 +67,10 @@ struct tahoe_forest {
     tahoe_sstate *sp = nullptr;    // non-null: this handle is a sparse forest (sparse.hip); the dense views are unused
     tahoe_pstate *pipe = nullptr;  // tahoe_forest_predict_host: chunk buffers, streams, events (created on first use)
     size_t device_bytes = 0;
+    // Tuning knobs for experiments, read from the environment ONCE, in tahoe_forest_create (never on the predict path):
+    // TAHOE_TILE_ROWS (64 / 128: rows per TILEBLOCK / TILERING tile), TAHOE_QRING_WALKERS (15 / 12 / 8 / 4).  0 = unset.
+    int knob_tile_rows = 0;
+    int knob_qring_walkers = 0;
     // Profiling: one hipEvent pair per traversal launch, read back after the stream has drained.
     bool profiling = false;
     std::vector<hipEvent_t> ev_start, ev_mid, ev_stop;  // mid: between a pre-pass kernel and the walk kernel
@@ -113,7 +117,7 @@ int qring_walkers(const tahoe_forest *f);  // walker waves the kernel would use;
 long long qring_lds_bytes(const tahoe_forest *f);
 // mid_event (optional) is recorded between the quantise kernel and the walk kernel
 tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, const float *data, size_t rows,
-                          hipStream_t stream, hipEvent_t mid_event);
+                          hipStream_t stream, hipEvent_t mid_event, const float *sums_in = nullptr);
 tahoe_status qring_reserve(tahoe_forest *f, size_t rows);
 int qwide_rows(const tahoe_forest *f);   // rows per tile of the wide-row form; 0 = not used
 bool qring_lds_tile(const tahoe_forest *f);
@@ -122,7 +126,7 @@ int qring_groups(const tahoe_forest *f);  // tree groups with separate quantisat
 // sparse forests (sparse.hip)
 bool sparse_tile_fits(const tahoe_forest *f);
 tahoe_status sparse_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, const float *data, size_t rows,
-                           hipStream_t stream, int strategy);
+                           hipStream_t stream, int strategy, const float *sums_in = nullptr);
 int sparse_top_waves(const tahoe_forest *f);
 void sparse_destroy(tahoe_forest *f);
 void pipeline_destroy(tahoe_forest *f);

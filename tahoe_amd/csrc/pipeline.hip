@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -75,31 +76,49 @@ static tahoe_status pipe_prepare(tahoe_forest *f, size_t chunk_rows, bool need_s
         f->pipe = ps = nullptr;
     }
     if (!ps) {
-        ps = new tahoe_pstate();
-        f->pipe = ps;
+        // Built in a local state and published only when complete: a failed allocation half-way frees what was
+        // made and leaves f->pipe null, so the next call starts over instead of reusing null buffers.
+        ps = new (std::nothrow) tahoe_pstate();
+        if (!ps) return fail(TAHOE_ERR_NO_MEMORY, "tahoe_forest_predict_host");
         ps->chunk_rows = chunk_rows;
         ps->cols = f->p.num_cols;
         const size_t dbytes = std::max<size_t>(chunk_rows * (size_t)f->p.num_cols * sizeof(float), 4);
         const size_t pbytes = std::max<size_t>(chunk_rows * sizeof(float), 4);
-        for (int s = 0; s < 2; ++s) {
-            TAHOE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ps->d_data[s]), dbytes));
-            TAHOE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ps->d_preds[s]), pbytes));
-            TAHOE_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ps->h_preds[s]), pbytes, hipHostMallocDefault));
-            TAHOE_HIP_TRY(hipEventCreateWithFlags(&ps->uploaded[s], hipEventDisableTiming));
-            TAHOE_HIP_TRY(hipEventCreateWithFlags(&ps->traversed[s], hipEventDisableTiming));
-            TAHOE_HIP_TRY(hipEventCreateWithFlags(&ps->returned[s], hipEventDisableTiming));
+        hipError_t e = hipSuccess;
+        auto ok = [&e](hipError_t r) { return e == hipSuccess && (e = r) == hipSuccess; };
+        for (int s = 0; s < 2 && e == hipSuccess; ++s) {
+            (void)(ok(hipMalloc(reinterpret_cast<void **>(&ps->d_data[s]), dbytes)) &&
+                   ok(hipMalloc(reinterpret_cast<void **>(&ps->d_preds[s]), pbytes)) &&
+                   ok(hipHostMalloc(reinterpret_cast<void **>(&ps->h_preds[s]), pbytes, hipHostMallocDefault)) &&
+                   ok(hipEventCreateWithFlags(&ps->uploaded[s], hipEventDisableTiming)) &&
+                   ok(hipEventCreateWithFlags(&ps->traversed[s], hipEventDisableTiming)) &&
+                   ok(hipEventCreateWithFlags(&ps->returned[s], hipEventDisableTiming)));
         }
-        TAHOE_HIP_TRY(hipStreamCreateWithFlags(&ps->copy, hipStreamNonBlocking));
-        TAHOE_HIP_TRY(hipStreamCreateWithFlags(&ps->compute, hipStreamNonBlocking));
-        TAHOE_HIP_TRY(hipStreamCreateWithFlags(&ps->back, hipStreamNonBlocking));
+        (void)(ok(hipStreamCreateWithFlags(&ps->copy, hipStreamNonBlocking)) &&
+               ok(hipStreamCreateWithFlags(&ps->compute, hipStreamNonBlocking)) &&
+               ok(hipStreamCreateWithFlags(&ps->back, hipStreamNonBlocking)));
+        if (e != hipSuccess) {
+            pipe_free(ps);
+            return fail(TAHOE_ERR_HIP, "tahoe_forest_predict_host: preparing the upload pipeline failed: %s", hipGetErrorString(e));
+        }
         // the quantised workspace is sized once for a chunk: no allocation inside the loop
-        tahoe_status st = qring_reserve(f, chunk_rows);
-        if (st != TAHOE_OK) return st;
+        const tahoe_status st = qring_reserve(f, chunk_rows);
+        if (st != TAHOE_OK) {
+            pipe_free(ps);
+            return st;
+        }
+        f->pipe = ps;
     }
     if (need_stage && !ps->h_stage[0]) {
         const size_t dbytes = std::max<size_t>(ps->chunk_rows * (size_t)f->p.num_cols * sizeof(float), 4);
-        for (int s = 0; s < 2; ++s)
-            TAHOE_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ps->h_stage[s]), dbytes, hipHostMallocDefault));
+        for (int s = 0; s < 2; ++s) {
+            const hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&ps->h_stage[s]), dbytes, hipHostMallocDefault);
+            if (e != hipSuccess) {  // all or nothing: a lone first buffer would read as "staging is ready"
+                if (ps->h_stage[0]) (void)hipHostFree(ps->h_stage[0]);
+                ps->h_stage[0] = ps->h_stage[1] = nullptr;
+                return fail(TAHOE_ERR_HIP, "tahoe_forest_predict_host: hipHostMalloc(stage) failed: %s", hipGetErrorString(e));
+            }
+        }
     }
     return TAHOE_OK;
 }

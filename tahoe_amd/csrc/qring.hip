@@ -48,7 +48,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                  const uint32_t *__restrict__ qinner, const uint32_t *__restrict__ leaf_orig, float *__restrict__ sums,
                  uint32_t *__restrict__ leaf_out, size_t rows, int cols, int num_trees, int depth, int top_levels,
                  int top_stride, const uint32_t *__restrict__ chunk_flags, int *__restrict__ error_flag,
-                 const float *__restrict__ sums_in, int tree_base, int total_trees, int cshift)
+                 const float *sums_in, int tree_base, int total_trees, int cshift)
 {
     constexpr int K = kQRows / 64;  // two 64-row chains per walker lane
     constexpr int NT = (NWALK + 1) * 64;
@@ -202,11 +202,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
         uint4 na_p[K] = {}, nb_p[K] = {};
         uint32_t bsel_p[K] = {};
         for (int t = wave; t < num_trees && !dead; t += NWALK) {
-#if defined(TAHOE_ABLATE) && (TAHOE_ABLATE & 2)
-            const bool more = false;  // timing-only build: every tree walks the first top
-#else
             const bool more = t + NWALK < num_trees;
-#endif
             if (more) prefetch_top(t + NWALK);
             uint32_t i[K];
     #pragma unroll
@@ -262,11 +258,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
             for (int k = 0; k < K; ++k) {
                 const uint4 *bp = blocks + ((size_t)t * n_blocks + bsel[k]) * 2;
                 na_p[k] = bp[0];  // node0, node1, node2, 0
-#if defined(TAHOE_ABLATE) && (TAHOE_ABLATE & 1)
-                nb_p[k] = na_p[k];  // timing-only build: no leaf gather
-#else
                 nb_p[k] = bp[1];  // four leaf values
-#endif
                 bsel_p[k] = bsel[k];
             }
             if (more) commit_top();  // this wave's reads of its slot are done (in-order LDS)
@@ -297,7 +289,7 @@ __global__ void __launch_bounds__(16 * 64)
                  const uint32_t *__restrict__ qinner, const uint32_t *__restrict__ leaf_orig, float *__restrict__ sums,
                  uint32_t *__restrict__ leaf_out, size_t rows, int cols, int num_trees, int depth, int top_levels,
                  int top_stride, const uint32_t *__restrict__ chunk_flags, int *__restrict__ error_flag,
-                 const float *__restrict__ sums_in, int tree_base, int total_trees, int slot_bytes, int lw, int cshift)
+                 const float *sums_in, int tree_base, int total_trees, int slot_bytes, int lw, int cshift)
 {
     constexpr int NWALK = 15;
     constexpr int NT = (NWALK + 1) * 64;
@@ -519,11 +511,9 @@ int qring_walkers(const tahoe_forest *f)
     if (!f->q) return 0;
     if (f->q->narrow) return 15;  // the node words were encoded for that form at create
     static const int options[] = {15, 12, 8, 4};
-    if (const char *e = getenv("TAHOE_QRING_WALKERS")) {  // tuning knob for experiments
-        const int want = atoi(e);
+    if (const int want = f->knob_qring_walkers)  // TAHOE_QRING_WALKERS, read at create
         for (int n : options)
             if (n == want && qring_lds_for(f, n) <= f->lds_limit) return n;
-    }
     for (int n : options)
         if (qring_lds_for(f, n) <= f->lds_limit) return n;
     return kGxWalkers;  // rows too wide for an LDS tile: features are read from the quantised tile in L2
@@ -798,7 +788,7 @@ static void qwide_launch(tahoe_forest *f, const tahoe_qgroup &g, float *sums, co
 }
 
 tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, const float *data, size_t rows,
-                          hipStream_t stream, hipEvent_t mid_event)
+                          hipStream_t stream, hipEvent_t mid_event, const float *sums_in0)
 {
     tahoe_qstate *q = f->q;
     const int nwalk = qring_walkers(f);
@@ -822,7 +812,7 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
         }
         TAHOE_HIP_TRY(hipGetLastError());
         if (first && mid_event) TAHOE_HIP_TRY(hipEventRecord(mid_event, stream));  // splits pre-pass / walk for 1 group
-        const float *sums_in = first ? nullptr : sums;  // later groups continue the running float32 sums
+        const float *sums_in = first ? sums_in0 : sums;  // later groups continue the running float32 sums
         if (wide == 64)
             qwide_launch<64>(f, g, sums, sums_in, leaf_out, rows, stream, cshift);
         else if (wide == 32)

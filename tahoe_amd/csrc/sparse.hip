@@ -44,7 +44,8 @@ template <bool TILE, bool WRITE_LEAF>
 __global__ void __launch_bounds__(kBlock) sparse_kernel(const tahoe_sparse_node *__restrict__ nodes,
                                                         const int32_t *__restrict__ trees, const float *__restrict__ data,
                                                         float *__restrict__ sums, uint32_t *__restrict__ leaf_out,
-                                                        size_t rows, int cols, int num_trees, float missing, int vec4_ok)
+                                                        const float *sums_in, size_t rows, int cols, int num_trees, float missing,
+                                                        int vec4_ok)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -71,6 +72,7 @@ __global__ void __launch_bounds__(kBlock) sparse_kernel(const tahoe_sparse_node 
         __syncthreads();
     }
     float sum = 0.0f;  // lanes 0..15: row 16*wave + lane of the tile
+    if (sums_in && lane < 16 && row0 + 16 * wave + lane < rows) sum = sums_in[row0 + 16 * wave + lane];
     const int rounds = (num_trees + kWaves - 1) / kWaves;
     for (int r = 0; r < rounds; ++r) {
         const int t = r * kWaves + wave;
@@ -128,9 +130,9 @@ constexpr int kSSpinLimit = 1 << 22;
 template <int NW, bool WRITE_LEAF>
 __global__ void __launch_bounds__(NW * 64) sparse_top_kernel(const uint2 *__restrict__ cnodes, const int32_t *__restrict__ ctrees,
                                                              const uint32_t *__restrict__ corig, const float *__restrict__ data,
-                                                             float *__restrict__ sums, uint32_t *__restrict__ leaf_out, size_t rows,
-                                                             int cols, int num_trees, float missing, int vec4_ok,
-                                                             int *__restrict__ error_flag)
+                                                             float *__restrict__ sums, uint32_t *__restrict__ leaf_out,
+                                                             const float *sums_in, size_t rows, int cols, int num_trees, float missing,
+                                                             int vec4_ok, int *__restrict__ error_flag)
 {
     constexpr int NWALK = NW - 1;
     static_assert(kSRing >= 2 * kSBatch && kSRing > NWALK, "ring too small");
@@ -164,7 +166,7 @@ __global__ void __launch_bounds__(NW * 64) sparse_top_kernel(const uint2 *__rest
     if (wave == NWALK) {
         // ================= consumer: lane = row, trees in order =================
         __syncthreads();
-        float sum = 0.0f;
+        float sum = (sums_in && row_ok) ? sums_in[row] : 0.0f;
         bool dead = false;
         for (int t0 = 0; t0 < num_trees && !dead; t0 += kSBatch) {
             const int nb = min(kSBatch, num_trees - t0);
@@ -277,7 +279,7 @@ static long long sparse_lds(const tahoe_forest *f, bool tile)
 bool sparse_tile_fits(const tahoe_forest *f) { return f->p.num_cols >= 1 && sparse_lds(f, true) <= f->lds_limit; }
 
 tahoe_status sparse_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, const float *data, size_t rows,
-                           hipStream_t stream, int strategy)
+                           hipStream_t stream, int strategy, const float *sums_in)
 {
     const tahoe_sstate *sp = f->sp;
     const unsigned grid = (unsigned)((rows + kTileRows - 1) / kTileRows);
@@ -288,7 +290,7 @@ tahoe_status sparse_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, con
         const int lds = (int)sparse_top_lds(f, nw);
 #define TAHOE_SPARSE_TOP(NW_, LEAF_)                                                                                     \
     hipLaunchKernelGGL((sparse_top_kernel<NW_, LEAF_>), dim3(grid), dim3(NW_ * 64), lds, stream, sp->cnodes, sp->ctrees, \
-                       sp->corig, data, sums, leaf_out, rows, f->p.num_cols, f->p.num_trees, f->p.missing, vec4_ok, f->error_flag)
+                       sp->corig, data, sums, leaf_out, sums_in, rows, f->p.num_cols, f->p.num_trees, f->p.missing, vec4_ok, f->error_flag)
         if (nw == 16) {
             if (leaf_out)
                 TAHOE_SPARSE_TOP(16, true);
@@ -308,7 +310,7 @@ tahoe_status sparse_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, con
     const int lds = (int)sparse_lds(f, tile);
 #define TAHOE_SPARSE_LAUNCH(TILE_, LEAF_)                                                                            \
     hipLaunchKernelGGL((sparse_kernel<TILE_, LEAF_>), dim3(grid), dim3(kBlock), lds, stream, sp->nodes, sp->trees, data, \
-                       sums, leaf_out, rows, f->p.num_cols, f->p.num_trees, f->p.missing, vec4_ok)
+                       sums, leaf_out, sums_in, rows, f->p.num_cols, f->p.num_trees, f->p.missing, vec4_ok)
     if (tile) {
         if (leaf_out)
             TAHOE_SPARSE_LAUNCH(true, true);

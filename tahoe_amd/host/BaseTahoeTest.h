@@ -281,16 +281,24 @@ class BaseTahoeTest {
         check(tahoe_device_alloc((void **)&preds_d, (size_t)ps.num_rows * sizeof(float), 1), "tahoe_device_alloc(preds_d)");
     }
 
-    // `warm` untimed + `timed` timed predicts on `stream`; returns µs per sample.
+    // `warm` untimed + `timed` timed predicts on `stream`; returns µs per sample, or FLT_MAX when a predict failed or
+    // a kernel raised the handle's error flag (tahoe_forest_check) -- preds_d is cleared first, so that a strategy
+    // that produced nothing cannot pass the comparison on the previous strategy's output.
     float time_predicts(int warm, int timed)
     {
-        for (int i = 0; i < warm; ++i) tahoe_forest_predict(forest, preds_d, data_d, (size_t)ps.num_rows, stream);
+        bool ok = tahoe_device_memset(preds_d, 0, (size_t)ps.num_rows * sizeof(float), stream) == TAHOE_OK;
+        for (int i = 0; i < warm && ok; ++i) ok = tahoe_forest_predict(forest, preds_d, data_d, (size_t)ps.num_rows, stream) == TAHOE_OK;
         tahoe_device_synchronize();
         struct timeval start, end;
         gettimeofday(&start, NULL);
-        for (int i = 0; i < timed; ++i) tahoe_forest_predict(forest, preds_d, data_d, (size_t)ps.num_rows, stream);
+        for (int i = 0; i < timed && ok; ++i) ok = tahoe_forest_predict(forest, preds_d, data_d, (size_t)ps.num_rows, stream) == TAHOE_OK;
         tahoe_device_synchronize();
         gettimeofday(&end, NULL);
+        if (ok) ok = tahoe_forest_check(forest, stream) == TAHOE_OK;
+        if (!ok) {
+            printf("FAIL: predict. Reason:%s\n", tahoe_last_error());
+            return FLT_MAX;
+        }
         const float us = (end.tv_sec - start.tv_sec) * 1000000.0f + (end.tv_usec - start.tv_usec);
         return us / ps.num_rows / timed;
     }
@@ -323,6 +331,10 @@ class BaseTahoeTest {
             }
             printf("Using strategy %d\n", loop + 1);
             acc[loop] = time_predicts(5, epoch_new);
+            if (acc[loop] == FLT_MAX) {  // a failed launch / raised error flag: same line as an infeasible strategy
+                printf("Strategy %d is not suitable for this case.\n", loop + 1);
+                continue;
+            }
             printf("Exec.Time/Sample on strategy %d is %f us\n", loop + 1, acc[loop]);
             report_compare();
         }
