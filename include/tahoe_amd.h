@@ -294,6 +294,13 @@ tahoe_status tahoe_copy_to_host(void *dst_host, const void *src_dev, size_t byte
 tahoe_status tahoe_stream_create(void **stream);
 tahoe_status tahoe_stream_destroy(void *stream);
 tahoe_status tahoe_stream_synchronize(void *stream);
+/* Events and device-to-device copies between GPUs of one process: what a host that chains tree shards over several
+ * devices needs (device g waits for device g-1's chunk, copies its running sums over xGMI, continues them). */
+tahoe_status tahoe_event_create(void **event);
+tahoe_status tahoe_event_destroy(void *event);
+tahoe_status tahoe_event_record(void *event, void *stream);
+tahoe_status tahoe_stream_wait_event(void *stream, void *event);
+tahoe_status tahoe_copy_peer(void *dst_dev, int dst_device, const void *src_dev, int src_device, size_t bytes, void *stream);
 tahoe_status tahoe_device_synchronize(void);
 tahoe_status tahoe_device_lds_bytes(int *bytes);  /* sharedMemPerBlock analogue, Struct.h:215-220 */
 /* compare_GPU, cuda_base.h:98-111: counts i with |a[i]-b[i]| > tol (on the device). */

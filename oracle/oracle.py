@@ -39,6 +39,10 @@ def _load():
     lib.oracle_predict.argtypes = [vp, i, i, vp, sz, sz, i, f, i, f, f, vp, vp]
     lib.oracle_predict_f64.restype = None
     lib.oracle_predict_f64.argtypes = [vp, i, i, vp, sz, sz, i, f, vp]
+    lib.oracle_predict_continue.restype = None
+    lib.oracle_predict_continue.argtypes = [vp, i, i, vp, sz, sz, i, f, vp]
+    lib.oracle_abs_leaf_sum.restype = None
+    lib.oracle_abs_leaf_sum.argtypes = [vp, i, i, vp, sz, sz, i, f, vp]
     lib.oracle_encode_node.restype = None
     lib.oracle_encode_node.argtypes = [vp, i, f, i, f, i]
     return lib
@@ -113,6 +117,49 @@ def predict_f64(nodes: np.ndarray, num_trees: int, depth: int, data: np.ndarray,
     lib.oracle_predict_f64(nodes.ctypes.data, num_trees, depth, data.ctypes.data, 0, rows, cols, missing,
                            sums.ctypes.data)
     return sums
+
+
+def _rows_in_threads(fn, rows: int, threads: int) -> None:
+    if threads <= 1 or rows < 2 * threads:
+        fn(0, rows)
+        return
+    bounds = np.linspace(0, rows, threads + 1).astype(np.int64)
+    with ThreadPoolExecutor(threads) as ex:  # ctypes releases the GIL during the call
+        list(ex.map(lambda k: fn(int(bounds[k]), int(bounds[k + 1])), range(threads)))
+
+
+def predict_f64_mt(nodes: np.ndarray, num_trees: int, depth: int, data: np.ndarray, missing: float, threads: int = 1) -> np.ndarray:
+    """predict_f64 with the rows split over `threads` host threads."""
+    nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
+    data = np.ascontiguousarray(data, dtype=np.float32)
+    rows, cols = data.shape
+    sums = np.empty(rows, dtype=np.float64)
+    _rows_in_threads(lambda lo, hi: lib.oracle_predict_f64(nodes.ctypes.data, num_trees, depth, data.ctypes.data, lo, hi, cols,
+                                                           missing, sums.ctypes.data), rows, threads)
+    return sums
+
+
+def predict_continue(nodes: np.ndarray, num_trees: int, depth: int, data: np.ndarray, missing: float, sums: np.ndarray,
+                     threads: int = 1) -> np.ndarray:
+    """In place: sums[i] <- sums[i] continued through the trees in order, float32 (a chained tree shard's step)."""
+    nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
+    data = np.ascontiguousarray(data, dtype=np.float32)
+    rows, cols = data.shape
+    assert sums.dtype == np.float32 and sums.shape == (rows,) and sums.flags.c_contiguous
+    _rows_in_threads(lambda lo, hi: lib.oracle_predict_continue(nodes.ctypes.data, num_trees, depth, data.ctypes.data, lo, hi, cols,
+                                                                missing, sums.ctypes.data), rows, threads)
+    return sums
+
+
+def abs_leaf_sum(nodes: np.ndarray, num_trees: int, depth: int, data: np.ndarray, missing: float, threads: int = 1) -> np.ndarray:
+    """float64 sum over trees of |leaf value| per row: the A of the float32 summation error bound gamma(n) * A."""
+    nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
+    data = np.ascontiguousarray(data, dtype=np.float32)
+    rows, cols = data.shape
+    out = np.empty(rows, dtype=np.float64)
+    _rows_in_threads(lambda lo, hi: lib.oracle_abs_leaf_sum(nodes.ctypes.data, num_trees, depth, data.ctypes.data, lo, hi, cols,
+                                                            missing, out.ctypes.data), rows, threads)
+    return out
 
 
 # ---- sparse forests (Struct.h:50-54, 2217-2250; BaseTahoeTest.h:728-764) ----

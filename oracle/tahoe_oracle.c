@@ -161,6 +161,34 @@ void oracle_predict_f64(const oracle_node *nodes, int num_trees, int depth, cons
     }
 }
 
+/* Checkers of the multi-GPU tree shards (no counterpart in the single-GPU reference).
+ * oracle_predict_continue: the loop of BaseTahoeTest.h:462-466 started from sums[i] instead of 0.0f, i.e. what shard k
+ * of a chained predict must produce from shard k-1's output; with sums = 0 it is oracle_predict with output = RAW.
+ * oracle_abs_leaf_sum: sum over trees of |leaf value| in float64, the A of the error bound gamma(n) * A. */
+void oracle_predict_continue(const oracle_node *nodes, int num_trees, int depth, const float *data,
+                             size_t row_begin, size_t row_end, int num_cols, float missing, float *sums)
+{
+    size_t num_nodes = (size_t)oracle_tree_num_nodes(depth);
+    for (size_t i = row_begin; i < row_end; ++i) {
+        float pred = sums[i];
+        for (int j = 0; j < num_trees; ++j)
+            pred += oracle_infer_one_tree(&nodes[(size_t)j * num_nodes], &data[i * (size_t)num_cols], missing, NULL);
+        sums[i] = pred;
+    }
+}
+
+void oracle_abs_leaf_sum(const oracle_node *nodes, int num_trees, int depth, const float *data,
+                         size_t row_begin, size_t row_end, int num_cols, float missing, double *sums)
+{
+    size_t num_nodes = (size_t)oracle_tree_num_nodes(depth);
+    for (size_t i = row_begin; i < row_end; ++i) {
+        double s = 0.0;
+        for (int j = 0; j < num_trees; ++j)
+            s += fabs((double)oracle_infer_one_tree(&nodes[(size_t)j * num_nodes], &data[i * (size_t)num_cols], missing, NULL));
+        sums[i] = s;
+    }
+}
+
 /* ------------------------------------------------------------------------------------------------
  * Sparse forests (dead code in the reference; the only reference-defined format that can hold the
  * irregular config K5).  See tahoe_oracle.h for the choice of branch rule. */

@@ -67,6 +67,11 @@ void oracle_predict(const oracle_node *nodes, int num_trees, int depth, const fl
  * far the float32 sequential sum is from the exact one). */
 void oracle_predict_f64(const oracle_node *nodes, int num_trees, int depth, const float *data,
                         size_t row_begin, size_t row_end, int num_cols, float missing, double *sums);
+/* Checkers of the multi-GPU tree shards (see tahoe_oracle.c). */
+void oracle_predict_continue(const oracle_node *nodes, int num_trees, int depth, const float *data,
+                             size_t row_begin, size_t row_end, int num_cols, float missing, float *sums);
+void oracle_abs_leaf_sum(const oracle_node *nodes, int num_trees, int depth, const float *data,
+                         size_t row_begin, size_t row_end, int num_cols, float missing, double *sums);
 
 /* ---- sparse forests: sparse_node_t (Struct.h:50-54), sparse_tree / sparse_storage (Struct.h:334-354) ---- */
 typedef struct {

@@ -156,6 +156,11 @@ _PROTOS = {
     "tahoe_stream_create": (_i, [C.POINTER(_vp)]),
     "tahoe_stream_destroy": (_i, [_vp]),
     "tahoe_stream_synchronize": (_i, [_vp]),
+    "tahoe_event_create": (_i, [C.POINTER(_vp)]),
+    "tahoe_event_destroy": (_i, [_vp]),
+    "tahoe_event_record": (_i, [_vp, _vp]),
+    "tahoe_stream_wait_event": (_i, [_vp, _vp]),
+    "tahoe_copy_peer": (_i, [_vp, _i, _vp, _i, _sz, _vp]),
     "tahoe_device_synchronize": (_i, []),
     "tahoe_device_lds_bytes": (_i, [C.POINTER(_i)]),
     "tahoe_compare_device": (_i, [_vp, _vp, _sz, _f, C.POINTER(_sz), _vp]),

@@ -153,6 +153,46 @@ tahoe_status tahoe_stream_synchronize(void *stream)
     return TAHOE_OK;
 }
 
+tahoe_status tahoe_event_create(void **event)
+{
+    if (!event) return fail(TAHOE_ERR_INVALID_ARG, "null argument");
+    hipEvent_t e;
+    TAHOE_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *event = (void *)e;
+    return TAHOE_OK;
+}
+
+tahoe_status tahoe_event_destroy(void *event)
+{
+    if (event) TAHOE_HIP_TRY(hipEventDestroy((hipEvent_t)event));
+    return TAHOE_OK;
+}
+
+tahoe_status tahoe_event_record(void *event, void *stream)
+{
+    if (!event) return fail(TAHOE_ERR_INVALID_ARG, "null argument");
+    TAHOE_HIP_TRY(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+    return TAHOE_OK;
+}
+
+tahoe_status tahoe_stream_wait_event(void *stream, void *event)
+{
+    if (!event) return fail(TAHOE_ERR_INVALID_ARG, "null argument");
+    TAHOE_HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+    return TAHOE_OK;
+}
+
+tahoe_status tahoe_copy_peer(void *dst_dev, int dst_device, const void *src_dev, int src_device, size_t bytes, void *stream)
+{
+    if (bytes && (!dst_dev || !src_dev)) return fail(TAHOE_ERR_INVALID_ARG, "null argument");
+    if (bytes == 0) return TAHOE_OK;
+    if (dst_device == src_device)
+        TAHOE_HIP_TRY(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    else
+        TAHOE_HIP_TRY(hipMemcpyPeerAsync(dst_dev, dst_device, src_dev, src_device, bytes, (hipStream_t)stream));
+    return TAHOE_OK;
+}
+
 tahoe_status tahoe_device_synchronize(void)
 {
     TAHOE_HIP_TRY(hipDeviceSynchronize());

@@ -51,16 +51,38 @@ def test_cli_result_json_and_leaf_dump(built, tmp_path):
     assert np.array_equal(got, want_leaf)
 
 
-@pytest.mark.parametrize("args", [["1"], ["--emulate", "3"], ["--emulate", "7"]])
+@pytest.mark.parametrize("args", [["1"], ["1", "--mode", "allreduce32"], ["1", "--mode", "chain", "--chunk", "100"],
+                                  ["--emulate", "3"], ["--emulate", "7", "--mode", "allreduce32"],
+                                  ["--emulate", "3", "--mode", "chain", "--chunk", "64"]])
 def test_sharded_host(built, args):
-    """./TahoeSharded: the C++ tree-sharding host (one process, a forest shard per device, one ncclAllReduce per
-    batch).  A 1-GPU box can check the RCCL path with a single shard (bit-exact) and the partition logic with shards
-    emulated on device 0 (partials added in shard order, 1e-6 relative)."""
+    """./TahoeSharded: the C++ tree-sharding host (one process, a forest shard per device).  A 1-GPU box can check the
+    RCCL path with a single shard (bit-exact) and the partition + combination logic with shards emulated on device 0:
+    all-reduce modes against the float64 sum with the stated bound, chain mode bit for bit."""
     exe = os.path.join(ROOT, "tahoe_amd", "host", "TahoeSharded")
     g = os.path.join(ROOT, "tests", "golden", "susy_like_c18")
     r = subprocess.run([exe, g + ".model.txt", g + ".data.txt"] + args, capture_output=True, text=True, timeout=180)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Results are correct" in r.stdout and "Exec.Time/Sample with" in r.stdout
+
+
+@pytest.mark.parametrize("mode", ["allreduce64", "allreduce32", "chain"])
+def test_sharded_host_1200_trees(built, tmp_path, mode):
+    """The same on a forest where float32 association matters (1200 trees): 8 emulated shards.  The gate inside
+    TahoeSharded is the float64 bound (all-reduce modes) / bit equality with the sequential float32 sum (chain)."""
+    import tahoe_amd as ta
+
+    T, D, C, R = 1200, 6, 16, 3000
+    nodes = ta.synth_forest(T, D, C, seed=11, leaf_prob=0.05)
+    data = ta.synth_data(R, C, seed=12, missing_prob=0.02, missing=-999.0)
+    ta.capi.write_model(str(tmp_path / "m.txt"), nodes, T, D)
+    ta.capi.write_data(str(tmp_path / "d.txt"), data, -999.0)
+    exe = os.path.join(ROOT, "tahoe_amd", "host", "TahoeSharded")
+    r = subprocess.run([exe, str(tmp_path / "m.txt"), str(tmp_path / "d.txt"), "--emulate", "8", "--mode", mode, "--chunk", "1000"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Results are correct" in r.stdout
+    if mode == "chain":
+        assert "max |ours - CPU float32 sum| = 0" in r.stdout
 
 
 def test_cli_unreadable_file_exits_1(built):

@@ -253,6 +253,53 @@ def test_k3_full_size_properties(env):
     assert np.array_equal(bits(r_sums), bits(got[:100_003]))
 
 
+def test_predict_accumulate_continues_the_sum_on_every_strategy(env):
+    """tahoe_forest_predict_accumulate: the per-row accumulator starts from the given running sums, so two shards
+    chained in tree order reproduce the single sequential float32 sum bit for bit -- dense strategies, tree groups,
+    wide rows, and a sparse handle."""
+    ta, oracle, torch = env
+    rng = np.random.default_rng(5)
+    for (T, D, C, R, lp) in [(50, 6, 32, 1000, 0.1), (700, 8, 4, 500, 0.0), (40, 7, 600, 300, 0.0), (9, 3, 5, 77, 0.2)]:
+        nodes = ta.synth_forest(T, D, C, seed=7, leaf_prob=lp)
+        data = ta.synth_data(R, C, seed=8, missing_prob=0.05, missing=MISSING)
+        x = torch.from_numpy(data).cuda()
+        start = rng.standard_normal(R).astype(np.float32)
+        want = oracle.predict_continue(nodes, T, D, data, MISSING, start.copy())
+        forest = ta.Forest(nodes, T, D, C, missing=MISSING)
+        info = forest.info()
+        strategies = [ta.STRATEGY_DIRECT, ta.STRATEGY_AUTO] + ([ta.STRATEGY_ROWTILE] if info.lds_bytes_per_block > 0 else []) + (
+            [ta.STRATEGY_TILEBLOCK] if info.tile_rows > 0 else []) + ([ta.STRATEGY_TILERING] if info.ring_rows > 0 else []) + (
+            [ta.STRATEGY_QRING] if info.qring_walkers > 0 else [])
+        for s in strategies:
+            forest.set_strategy(s)
+            got = forest.predict_accumulate(x, torch.from_numpy(start.copy()).cuda())
+            forest.check()
+            assert np.array_equal(bits(got.cpu().numpy()), bits(want)), (T, D, C, s)
+        # two shards chained == the whole forest
+        per = ta.capi.tree_num_nodes(D)
+        cut = T // 3
+        a = ta.Forest(nodes[: cut * per], cut, D, C, missing=MISSING)
+        b = ta.Forest(nodes[cut * per:], T - cut, D, C, missing=MISSING)
+        run = torch.zeros(R, dtype=torch.float32, device="cuda")
+        a.predict_accumulate(x, run)
+        b.predict_accumulate(x, run)
+        whole, _ = oracle.predict(nodes, T, D, data, MISSING)
+        assert np.array_equal(bits(run.cpu().numpy()), bits(whole))
+    # sparse handle
+    T, D, C, R = 30, 7, 20, 400
+    nodes = ta.synth_forest(T, D, C, seed=17, leaf_prob=0.15)
+    data = ta.synth_data(R, C, seed=18, missing_prob=0.05, missing=MISSING)
+    sn, tr = ta.capi.dense_to_sparse(nodes, T, D)
+    start = rng.standard_normal(R).astype(np.float32)
+    want = oracle.predict_continue(nodes, T, D, data, MISSING, start.copy())
+    f = ta.capi.SparseForest(sn, tr, C, missing=MISSING)
+    for s in (ta.STRATEGY_AUTO, ta.STRATEGY_ROWTILE, ta.STRATEGY_DIRECT):
+        f.set_strategy(s)
+        got = f.predict_accumulate(torch.from_numpy(data).cuda(), torch.from_numpy(start.copy()).cuda())
+        f.check()
+        assert np.array_equal(bits(got.cpu().numpy()), bits(want)), s
+
+
 # ---- the rank-quantised path (QRING): exactness at the edges of the float order ----
 
 def test_quantised_threshold_edge_values(env):
