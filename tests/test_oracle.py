@@ -77,6 +77,67 @@ def test_hand_derived_tree():
     assert preds.tolist() == [10.0, 2.0, 1.0, 2.0, 2.0, 1.0]
 
 
+def test_known_answers_every_branch_of_the_walk():
+    """Every branch of infer_one_tree (BaseTahoeTest.h:440-456), expected values written by hand -- none of them produced
+    by the code under test.  One depth-1 tree: root on feature 0 with threshold 0.5, left leaf -3, right leaf +4."""
+    M = -999.0
+
+    def stump(thr, def_left):
+        return enc([0, 0, 0], [thr, -3.0, 4.0], [def_left, 0, 0], [0, 0, 0], [0, 1, 1])
+
+    below = np.nextafter(np.float32(0.5), np.float32(0))  # 0.49999997
+    xs = np.array([0.5, below, 0.6, np.nan, np.inf, -np.inf, M, M + 5e-4, -0.0], dtype=np.float32).reshape(-1, 1)
+    #            tie->R  <->L  >->R  NaN->L  +inf->R  -inf->L  missing  next float after M: outside the band -> compare -> L
+    for def_left, at_missing in ((1, -3.0), (0, 4.0)):  # :452  missing ? !def_left : x >= thr
+        preds, leaf = oracle.predict(stump(0.5, def_left), 1, 1, xs, M, want_leaf=True)
+        assert preds.tolist() == [4.0, -3.0, 4.0, -3.0, 4.0, -3.0, at_missing, -3.0, -3.0]
+        assert leaf[:, 0].tolist() == [2, 1, 2, 1, 2, 1, 1 if def_left else 2, 1, 1]  # :453  curr = 2*curr + 1 + cond
+    # a NaN threshold is never reached by >= : everything that is not missing goes left
+    preds, _ = oracle.predict(stump(np.nan, 0), 1, 1, xs, M)
+    assert preds.tolist() == [-3.0, -3.0, -3.0, -3.0, -3.0, -3.0, 4.0, -3.0, -3.0]
+    # a NaN sentinel never matches (fabs(x - NaN) <= eps is false), not even a NaN feature
+    preds, _ = oracle.predict(stump(0.5, 0), 1, 1, xs, float("nan"))
+    assert preds.tolist() == [4.0, -3.0, 4.0, -3.0, 4.0, -3.0, -3.0, -3.0, -3.0]
+    # -0.0 == 0.0: a threshold of +0.0 sends -0.0 right (ties go right)
+    preds, _ = oracle.predict(stump(0.0, 0), 1, 1, np.array([[-0.0], [0.0], [-1e-45]], dtype=np.float32), M)
+    assert preds.tolist() == [4.0, 4.0, -3.0]
+    # a leaf at the root (:449 before any feature is read): depth 0, leaf index 0, features irrelevant
+    preds, leaf = oracle.predict(enc([5], [7.25], [0], [0], [1]), 1, 0, np.array([[np.nan]], dtype=np.float32), M, want_leaf=True)
+    assert preds.tolist() == [7.25] and leaf.tolist() == [[0]]
+    # the feature index comes from bits & FID_MASK with DEF_LEFT and IS_LEAF stripped (Struct.h:110-117): fid 3 of 4
+    nodes = enc([3, 0, 0], [0.5, -3.0, 4.0], [1, 0, 0], [0, 0, 0], [0, 1, 1])
+    preds, _ = oracle.predict(nodes, 1, 1, np.array([[9, 9, 9, 0.4], [0, 0, 0, 0.6]], dtype=np.float32), M)
+    assert preds.tolist() == [-3.0, 4.0]
+
+
+def test_known_answers_every_output_mode():
+    """predict_on_cpu's epilogue (BaseTahoeTest.h:467-472) in its order -- AVG (a DIVISION by num_trees), + bias, sigmoid,
+    threshold (strict >) -- with expectations written by hand.  Three single-leaf trees summing to 5.0."""
+    nodes = enc([0, 0, 0], [1.0, 1.5, 2.5], [0, 0, 0], [0, 0, 0], [1, 1, 1])
+    x = np.zeros((1, 1), np.float32)
+    RAW, AVG, SIG, THR = 0x0, 0x1, 0x10, 0x100
+
+    def run(output, threshold=0.0, bias=0.0):
+        return oracle.predict(nodes, 3, 0, x, -999.0, output, threshold, bias)[0]
+
+    assert run(RAW)[0] == 5.0
+    assert run(RAW, bias=0.25)[0] == 5.25                      # :468 the bias is added in RAW mode too
+    # 5/3 in float32 is 0x3FD55555 (1.6666666); 5 * fl(1/3) would be 0x3FD55556 -- the CPU predictor divides
+    assert run(AVG).view(np.uint32)[0] == 0x3FD55555
+    assert run(AVG, bias=-0.5).view(np.uint32)[0] == np.float32(np.float32(5.0) / np.float32(3.0) - np.float32(0.5)).view(np.uint32)
+    zero = enc([0, 0], [2.0, -2.0], [0, 0], [0, 0], [1, 1])  # two trees summing to 0
+    z = lambda output, threshold=0.0, bias=0.0: oracle.predict(zero, 2, 0, x, -999.0, output, threshold, bias)[0][0]  # noqa: E731
+    assert z(SIG) == 0.5                                        # 1 / (1 + exp(-0)) exactly
+    assert z(SIG | THR, threshold=0.5) == 0.0                   # strict: 0.5 > 0.5 is false
+    assert z(SIG | THR, threshold=0.49) == 1.0
+    assert z(THR, threshold=-0.1) == 1.0 and z(THR, threshold=0.0) == 0.0
+    assert z(AVG | SIG, bias=0.0) == 0.5
+    assert z(SIG, bias=200.0) == 1.0                            # exp(-200) underflows: 1 / (1 + 0)
+    assert z(SIG, bias=-200.0) == 0.0                           # expf(200) = inf: 1 / inf
+    assert z(AVG | SIG | THR, threshold=0.7, bias=1.0) == 1.0   # sigmoid(0/2 + 1) = 0.7310586 > 0.7
+    assert z(AVG | SIG | THR, threshold=0.74, bias=1.0) == 0.0
+
+
 def test_missing_band_is_on_the_float32_difference():
     # |x - missing| <= 1e-6f with the subtraction rounded to float32 (BaseTahoeTest.h:451-452)
     m = np.float32(0.25)
