@@ -123,6 +123,8 @@ def main():
     ap.add_argument("--chunk-rows", type=int, default=32768, help="rows per hand-over of the chained tree shards")
     ap.add_argument("--strategy", type=int, default=0, help="0 auto, 1 direct, 2 rowtile, 3 tileblock, 4 tilering, 5 qring")
     ap.add_argument("--cpu-rows", type=int, default=100_000, help="rows of the batch timed on the CPU oracle")
+    ap.add_argument("--relayout", action="store_true",
+                    help="probability-guided re-layout (SURVEY 8f N3): weights = reach probabilities, TAHOE_CREATE_PROB_RELAYOUT")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-host", action="store_true", help="skip the host-resident (PCIe-inclusive) leg")
     ap.add_argument("--no-k4", "--no-tree-leg", dest="no_k4", action="store_true", help="skip the secondary K4 legs")
@@ -194,6 +196,8 @@ def main():
 
     T, D, C, R = args.trees, args.depth, args.cols, args.rows
     nodes = ta.synth_forest(T, D, C, seed=42)
+    if args.relayout:
+        ta.capi.set_probability_weights(nodes, T, D)
     n_per_tree = ta.capi.tree_num_nodes(D)
     tree_sharded = world > 1 and args.shard == "trees"
     weak = world > 1 and args.shard == "rows" and args.scaling == "weak"
@@ -219,7 +223,7 @@ def main():
         forest.set_strategy(args.strategy)
         my_T = forest.num_trees
     else:
-        forest = ta.Forest(nodes, T, D, C, missing=MISSING)
+        forest = ta.Forest(nodes, T, D, C, missing=MISSING, relayout=args.relayout)
         forest.set_strategy(args.strategy)
         my_T = T
     forest.reserve(min(my_rows, args.chunk_rows) if (tree_sharded and args.tree_mode == "chain") else my_rows)
@@ -382,7 +386,8 @@ def main():
             "config": {"workload": f"K3: synthetic forest {T} trees depth {D}, {C} features, {R} rows"
                                    + (" per GPU" if weak else (f" split over {world} GPUs" if world > 1 else "")),
                        "trees": T, "depth": D, "cols": C, "rows_per_step": total_rows, "rows_per_gpu": my_rows,
-                       "sharding": sharding_name, "strategy": strategy_name},
+                       "sharding": sharding_name, "strategy": strategy_name,
+                       **({"relayout_swaps": int(info.relayout_swaps)} if args.relayout else {})},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "host_pipeline": host_leg,

@@ -128,6 +128,17 @@ typedef struct tahoe_forest tahoe_forest; /* opaque */
  * reachable fid < num_cols (the reference reads out of bounds instead). */
 tahoe_status tahoe_forest_create(tahoe_forest **out, const tahoe_dense_node *nodes,
                                  const tahoe_forest_params *params);
+/* The same with options.  TAHOE_CREATE_PROB_RELAYOUT: the reference's probability-guided re-layout
+ * (dense_adaptive_forest::init, Struct.h:1775-1825; swap_child :1712-1750): bottom-up, wherever dense_node_t.weight of
+ * a node's left child is smaller than that of its right child, the two subtrees change places and the node is marked
+ * "exchange" (the walk inverts its condition there, Struct.h:1060-1063), so that the likelier child is always the left
+ * one and hot paths sit next to each other in memory.  Results are unchanged: leaf indices are still reported in the
+ * original heap numbering.  Served by the strategies whose node words have a spare bit (DIRECT, ROWTILE, and QRING
+ * when num_cols <= 256); without the flag `weight` is ignored, as in round 1.  tahoe_forest_create honours the
+ * environment variable TAHOE_RELAYOUT=1 (read once, at create) for experiments. */
+#define TAHOE_CREATE_PROB_RELAYOUT 0x1u
+tahoe_status tahoe_forest_create_ex(tahoe_forest **out, const tahoe_dense_node *nodes,
+                                    const tahoe_forest_params *params, unsigned flags);
 void tahoe_forest_destroy(tahoe_forest *f);
 
 /* ---- sparse (irregular) forests: sparse_node_t Struct.h:50-54, sparse_storage Struct.h:343-354,
@@ -229,6 +240,8 @@ typedef struct {
     int tilering_lds_bytes;  /* dynamic LDS of the TILERING kernel */
     int qring_tile_rows;     /* rows per quantised tile in LDS: 128, or 64 / 32 / 16 for wide rows (several trees per
                               * wave); 0 = features read from the quantised tile in L2, or QRING unavailable */
+    int relayout;            /* 1: created with TAHOE_CREATE_PROB_RELAYOUT */
+    size_t relayout_swaps;   /* internal nodes whose subtrees changed places */
 } tahoe_forest_info;
 tahoe_status tahoe_forest_get_info(const tahoe_forest *f, tahoe_forest_info *info);
 

@@ -33,6 +33,7 @@ lib = C.CDLL(LIB_PATH)
 # ---- constants mirrored from the header ----
 OUT_RAW, OUT_AVG, OUT_SIGMOID, OUT_THRESHOLD = 0x0, 0x1, 0x10, 0x100
 STRATEGY_AUTO, STRATEGY_DIRECT, STRATEGY_ROWTILE, STRATEGY_TILEBLOCK, STRATEGY_TILERING, STRATEGY_QRING = range(6)
+CREATE_PROB_RELAYOUT = 0x1
 STRATEGY_NAMES = {1: "direct", 2: "rowtile", 3: "tileblock", 4: "tilering", 5: "qring"}
 STATUS_NAMES = {
     0: "TAHOE_OK",
@@ -88,6 +89,8 @@ class ForestInfo(C.Structure):
         ("ring_rows", C.c_int),
         ("tilering_lds_bytes", C.c_int),
         ("qring_tile_rows", C.c_int),
+        ("relayout", C.c_int),
+        ("relayout_swaps", C.c_size_t),
     ]
 
 
@@ -111,6 +114,7 @@ _PROTOS = {
     "tahoe_decode_node": (None, [_vp] + [_vp] * 5),
     "tahoe_tree_num_nodes": (_i, [_i]),
     "tahoe_forest_create": (_i, [C.POINTER(_vp), _vp, C.POINTER(ForestParams)]),
+    "tahoe_forest_create_ex": (_i, [C.POINTER(_vp), _vp, C.POINTER(ForestParams), C.c_uint]),
     "tahoe_forest_destroy": (None, [_vp]),
     "tahoe_sparse_forest_create": (_i, [C.POINTER(_vp), _vp, _vp, C.POINTER(ForestParams)]),
     "tahoe_dense_to_sparse": (_i, [_vp, _i, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_sz)]),
@@ -285,6 +289,27 @@ def synth_data(rows: int, num_cols: int, seed: int = 43, missing_prob: float = 0
     return data
 
 
+def set_probability_weights(nodes: np.ndarray, num_trees: int, depth: int, lo: float = -1.0, hi: float = 1.0) -> np.ndarray:
+    """Fills dense_node_t.weight with the probability of reaching each node for features uniform in [lo, hi) and
+    independent (what synth_data draws): root 1, left child p * P(x < thr), right child p * P(x >= thr).  Input
+    preparation for the probability-guided re-layout (a trained model carries such weights from its training data)."""
+    per = tree_num_nodes(depth)
+    n = nodes.reshape(num_trees, per)
+    w = np.zeros((num_trees, per), dtype=np.float64)
+    w[:, 0] = 1.0
+    thr = n["val"].astype(np.float64)
+    is_leaf = (n["bits"].view(np.uint32) >> 31) != 0
+    for level in range(depth):
+        a, b = (1 << level) - 1, (2 << level) - 1
+        p_right = np.clip((hi - thr[:, a:b]) / (hi - lo), 0.0, 1.0)
+        p_right = np.where(np.isnan(p_right), 0.0, p_right)
+        live = np.where(is_leaf[:, a:b], 0.0, w[:, a:b])  # nothing is reached below a leaf
+        w[:, 2 * a + 1: 2 * b + 1: 2] = live * (1.0 - p_right)
+        w[:, 2 * a + 2: 2 * b + 2: 2] = live * p_right
+    n["weight"] = w.astype(np.float32)
+    return nodes
+
+
 def encode_nodes(fid, value, def_left, weight, is_leaf) -> np.ndarray:
     """Vector form of encode_node (Struct.h:103-108) for building test forests by hand."""
     fid = np.asarray(fid, dtype=np.int64)
@@ -319,15 +344,19 @@ class Forest:
 
     def __init__(self, nodes: np.ndarray, num_trees: int, depth: int, num_cols: int, missing: float = 0.0,
                  output: int = OUT_RAW, threshold: float = 0.0, global_bias: float = 0.0, algo: int = 0,
-                 strategy: int = 0):
+                 strategy: int = 0, relayout: bool = False):
         nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
         if nodes.size != num_trees * tree_num_nodes(depth):
             raise ValueError("nodes.size != num_trees * tree_num_nodes(depth)")
         self.params = ForestParams(0, depth, num_trees, num_cols, algo, output, threshold, global_bias, strategy,
                                    missing)
         self._h = _vp()
-        _check(lib.tahoe_forest_create(C.byref(self._h), nodes.ctypes.data if nodes.size else None,
-                                       C.byref(self.params)), "tahoe_forest_create")
+        if relayout:  # TAHOE_CREATE_PROB_RELAYOUT: subtrees ordered by dense_node_t.weight (Struct.h:1775-1825)
+            _check(lib.tahoe_forest_create_ex(C.byref(self._h), nodes.ctypes.data if nodes.size else None,
+                                              C.byref(self.params), CREATE_PROB_RELAYOUT), "tahoe_forest_create_ex")
+        else:
+            _check(lib.tahoe_forest_create(C.byref(self._h), nodes.ctypes.data if nodes.size else None,
+                                           C.byref(self.params)), "tahoe_forest_create")
         self.num_trees, self.depth, self.num_cols = num_trees, depth, num_cols
 
     def close(self) -> None:

@@ -12,7 +12,7 @@
 //   above the bottom level is pushed down -- all bottom-level descendants inherit its value and
 //   remember its original heap index.  A walk is then exactly De compare-and-step iterations with
 //   no leaf test, so the 64 lanes of a wave never diverge.  Three views of the same tree t:
-//     (1) heap records          inner[t][2^De - 1] {float thr; uint32 meta}, meta = fid | def_left<<31
+//     (1) heap records          inner[t][2^De - 1] {float thr; uint32 meta}, meta = fid | exchange<<30 | def_left<<31
 //                               leaf_val[t][2^De] float, leaf_orig[t][2^De] uint32 (original heap index)
 //     (2) top, SoA (<=10 levels) top[t]: thr[2^L] float | meta[2^L] uint16 (fid | def_left<<15), indexed by
 //                               1-based heap position: staged whole into LDS by the TILEBLOCK kernel
@@ -42,7 +42,7 @@ namespace tahoe {
 // (go_right, the branch rule, lives in forest_internal.h)
 __device__ __forceinline__ uint32_t step(uint32_t idx, float thr, uint32_t meta, float x, float missing)
 {
-    return 2u * idx + 1u + go_right(x, thr, (meta >> 31) != 0, missing);
+    return 2u * idx + 1u + go_right_meta(x, thr, meta, missing);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(kBlock) direct_kernel(const InnerNode *__restr
         uint32_t idx = 0;
         for (int l = 0; l < depth; ++l) {
             const InnerNode n = tree[idx];
-            idx = step(idx, n.thr, n.meta, x[n.meta & 0x7fffffffu], missing);
+            idx = step(idx, n.thr, n.meta, x[n.meta & kMetaFidMask], missing);
         }
         const size_t b = (size_t)t * n_leaf + (idx - (uint32_t)n_inner);
         sum += leaf_val[b];
@@ -164,13 +164,13 @@ __global__ void __launch_bounds__(kBlock) rowtile_kernel(const InnerNode *__rest
             uint32_t idx = 0;
             for (int l = 0; l < lds_levels; ++l) {
                 const InnerNode n = slot[idx];
-                const float x = tile[(n.meta & 0x7fffffffu) * kTileRows + lane];
+                const float x = tile[(n.meta & kMetaFidMask) * kTileRows + lane];
                 idx = step(idx, n.thr, n.meta, x, missing);
             }
             const InnerNode *tree = inner + (size_t)t * n_inner;
             for (int l = lds_levels; l < depth; ++l) {
                 const InnerNode n = tree[idx];
-                const float x = tile[(n.meta & 0x7fffffffu) * kTileRows + lane];
+                const float x = tile[(n.meta & kMetaFidMask) * kTileRows + lane];
                 idx = step(idx, n.thr, n.meta, x, missing);
             }
             const size_t b = (size_t)t * n_leaf + (idx - (uint32_t)n_inner);
@@ -333,7 +333,7 @@ __global__ void __launch_bounds__(kSlots *ROWS)
                 const InnerNode *tree = inner + (size_t)t * n_inner;
                 for (int l = top_levels; l < depth - 2; ++l) {
                     const InnerNode n = tree[idx];
-                    const float x = tile[(n.meta & 0x7fffffffu) * ROWS + rloc];
+                    const float x = tile[(n.meta & kMetaFidMask) * ROWS + rloc];
                     idx = step(idx, n.thr, n.meta, x, missing);
                 }
             }
@@ -577,7 +577,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                 const InnerNode *tree = inner + (size_t)t * n_inner;
                 for (int l = top_levels; l < depth - 2; ++l) {
                     const InnerNode n = tree[idx];
-                    const float x = tile[(n.meta & 0x7fffffffu) * ROWS + k * 64 + lane];
+                    const float x = tile[(n.meta & kMetaFidMask) * ROWS + k * 64 + lane];
                     idx = step(idx, n.thr, n.meta, x, missing);
                 }
             }
@@ -895,7 +895,16 @@ extern "C" {
 
 tahoe_status tahoe_forest_create(tahoe_forest **out, const tahoe_dense_node *nodes, const tahoe_forest_params *p)
 {
+    unsigned flags = 0;
+    if (const char *e = getenv("TAHOE_RELAYOUT"))  // experiments: the re-layout without touching the caller
+        if (atoi(e) != 0) flags |= TAHOE_CREATE_PROB_RELAYOUT;
+    return tahoe_forest_create_ex(out, nodes, p, flags);
+}
+
+tahoe_status tahoe_forest_create_ex(tahoe_forest **out, const tahoe_dense_node *nodes, const tahoe_forest_params *p, unsigned flags)
+{
     if (!out || !p) return fail(TAHOE_ERR_INVALID_ARG, "tahoe_forest_create: null argument");
+    if ((flags & ~(unsigned)TAHOE_CREATE_PROB_RELAYOUT) != 0) return fail(TAHOE_ERR_INVALID_ARG, "unknown create flags 0x%x", flags);
     *out = nullptr;
     // check_params, BaseTahoeTest.h:490-516
     if (p->depth < 0 || p->depth > 30) return fail(TAHOE_ERR_INVALID_ARG, "depth must be in [0,30], got %d", p->depth);
@@ -935,7 +944,9 @@ tahoe_status tahoe_forest_create(tahoe_forest **out, const tahoe_dense_node *nod
     }
     if (const char *e = getenv("TAHOE_TILE_ROWS")) f->knob_tile_rows = atoi(e);
     if (const char *e = getenv("TAHOE_QRING_WALKERS")) f->knob_qring_walkers = atoi(e);
-    f->has_blocks = p->num_cols <= kBlockMaxCols;
+    f->relayout = (flags & TAHOE_CREATE_PROB_RELAYOUT) != 0;
+    // the float32 top / block views pack fid and def_left into 10 / 16 bits: no room for the exchange bit
+    f->has_blocks = p->num_cols <= kBlockMaxCols && !f->relayout;
 
     // ---- normalise: heap records of the perfect depth-De tree ----
     const size_t T = (size_t)p->num_trees;
@@ -1014,6 +1025,48 @@ tahoe_status tahoe_forest_create(tahoe_forest **out, const tahoe_dense_node *nod
                         "tree %zu: reachable bottom-level node %zu is not a leaf (the reference would walk out of the tree)",
                         bad.tree, bad.node);
         return fail(TAHOE_ERR_INVALID_FOREST, "tree %zu node %zu: fid %d >= num_cols %d", bad.tree, bad.node, bad.fid, num_cols);
+    }
+    // ---- probability-guided re-layout (dense_adaptive_forest::init step (ii), Struct.h:1775-1825 with
+    // swap_child :1712-1750): bottom-up, at every internal node whose left child weighs less than its right child the
+    // two subtrees change places and the node gets the exchange bit, so the likelier child is always the left one.
+    // leaf_orig moves with the leaves: leaf indices stay in the original heap numbering.
+    if (f->relayout) {
+        std::vector<size_t> swaps_of;
+        parallel_for(T, 8, [&, n_inner, n_leaf](size_t t_lo, size_t t_hi) {
+            std::vector<float> w(all_nodes);
+            size_t swaps = 0;
+            for (size_t t = t_lo; t < t_hi; ++t) {
+                const tahoe_dense_node *tree = nodes + t * src_nodes;
+                for (size_t i = 0; i < all_nodes; ++i) w[i] = i < src_nodes ? tree[i].weight : 0.0f;
+                InnerNode *in = &h_inner[t * n_inner];
+                unsigned char *re = &h_real[t * n_inner];
+                float *lv = &h_leaf[t * n_leaf];
+                uint32_t *lo = &h_orig[t * n_leaf];
+                for (int l = De - 1; l >= 0; --l) {
+                    for (size_t i = ((size_t)1 << l) - 1; i < ((size_t)2 << l) - 1; ++i) {
+                        if (!re[i]) continue;                    // padding below a leaf: nothing to order
+                        const size_t a = 2 * i + 1, b = 2 * i + 2;
+                        if (!(w[a] < w[b])) continue;            // Struct.h:1791: swap when the left child is the lighter one
+                        for (int d = 0;; ++d) {                  // the two subtrees, level by level
+                            const size_t sa = ((a + 1) << d) - 1, sb = ((b + 1) << d) - 1, len = (size_t)1 << d;
+                            if (sa >= n_inner) {                 // leaf level of the normalised tree
+                                std::swap_ranges(lv + (sa - n_inner), lv + (sa - n_inner) + len, lv + (sb - n_inner));
+                                std::swap_ranges(lo + (sa - n_inner), lo + (sa - n_inner) + len, lo + (sb - n_inner));
+                                break;
+                            }
+                            std::swap_ranges(in + sa, in + sa + len, in + sb);
+                            std::swap_ranges(re + sa, re + sa + len, re + sb);
+                            std::swap_ranges(w.begin() + sa, w.begin() + sa + len, w.begin() + sb);
+                        }
+                        in[i].meta |= kMetaExchange;
+                        ++swaps;
+                    }
+                }
+            }
+            std::lock_guard<std::mutex> lock(collect);
+            swaps_of.push_back(swaps);
+        });
+        for (size_t n : swaps_of) f->relayout_swaps += n;
     }
     int max_fid = 0;
     for (int m : max_fid_of) max_fid = std::max(max_fid, m);
@@ -1250,6 +1303,8 @@ tahoe_status tahoe_forest_get_info(const tahoe_forest *f, tahoe_forest_info *inf
     info->ring_rows = tilering_rows(f);
     info->tilering_lds_bytes = info->ring_rows ? (int)tilering_lds_bytes(f, info->ring_rows) : 0;
     info->qring_tile_rows = info->qring_walkers == 0 ? 0 : qwide_rows(f) ? qwide_rows(f) : qring_lds_tile(f) ? 128 : 0;
+    info->relayout = f->relayout ? 1 : 0;
+    info->relayout_swaps = f->relayout_swaps;
     return TAHOE_OK;
 }
 

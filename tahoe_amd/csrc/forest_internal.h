@@ -16,8 +16,10 @@ namespace tahoe {
 
 struct InnerNode {
     float thr;
-    uint32_t meta;  // fid | def_left << 31
+    uint32_t meta;  // fid (30 bits, FID_MASK of Struct.h:57) | exchange << 30 | def_left << 31
 };
+constexpr uint32_t kMetaFidMask = 0x3fffffffu;
+constexpr uint32_t kMetaExchange = 1u << 30;  // probability-guided re-layout: children stored swapped, condition inverted
 static_assert(sizeof(InnerNode) == 8, "InnerNode must be 8 bytes");
 
 constexpr int kBlock = 256;             // threads per workgroup of DIRECT / ROWTILE (4 waves)
@@ -69,6 +71,10 @@ struct tahoe_forest {
     size_t device_bytes = 0;
     // Tuning knobs for experiments, read from the environment ONCE, in tahoe_forest_create (never on the predict path):
     // TAHOE_TILE_ROWS (64 / 128: rows per TILEBLOCK / TILERING tile), TAHOE_QRING_WALKERS (15 / 12 / 8 / 4).  0 = unset.
+    // Probability-guided re-layout (TAHOE_CREATE_PROB_RELAYOUT; Struct.h:1775-1825): subtrees swapped so that the likelier
+    // child is the left one, nodes carry an exchange bit.  Served by DIRECT, ROWTILE and the NARROW form of QRING.
+    bool relayout = false;
+    size_t relayout_swaps = 0;
     int knob_tile_rows = 0;
     int knob_qring_walkers = 0;
     // Profiling: one hipEvent pair per traversal launch, read back after the stream has drained.
@@ -106,6 +112,11 @@ __device__ __forceinline__ uint32_t go_right(float x, float thr, bool def_left, 
     const bool is_missing = fabsf(x - missing) <= kMissingEps;
     const bool cond = is_missing ? !def_left : (x >= thr);
     return cond ? 1u : 0u;
+}
+// ... on a heap record: the stored children are swapped where the exchange bit is set (Struct.h:1060-1063: cond = !cond)
+__device__ __forceinline__ uint32_t go_right_meta(float x, float thr, uint32_t meta, float missing)
+{
+    return go_right(x, thr, (meta >> 31) != 0, missing) ^ ((meta >> 30) & 1u);
 }
 
 // QRING entry points (qring.hip).  h_real[i] != 0 marks heap records that exist in the original tree

@@ -42,7 +42,7 @@ namespace tahoe {
 // ------------------------------------------------------------------------------------------------
 // (2) the walk.  Dynamic LDS: tile [cols][128] u16 | NWALK slots of (4 << L) bytes | ring [16][128] f32 |
 // ready[16] | consumed.
-template <int NWALK, bool WRITE_LEAF, bool LDSX, bool NARROW = false>
+template <int NWALK, bool WRITE_LEAF, bool LDSX, bool NARROW = false, bool EXCH = false>
 __global__ void __launch_bounds__((NWALK + 1) * 64)
     qring_kernel(const uint16_t *__restrict__ xq, const uint32_t *__restrict__ top, const uint4 *__restrict__ blocks,
                  const uint32_t *__restrict__ qinner, const uint32_t *__restrict__ leaf_orig, float *__restrict__ sums,
@@ -170,9 +170,9 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
             for (int k = 0; k < K; ++k) {
                 // two dependent steps (the kernel is VALU-bound: this is ~half the instructions of evaluating
                 // both second-level nodes)
-                const bool c0 = q_go_right<MS, NARROW>(q_xread<LDSX, NARROW>(gx, na[k].x, pos[k]), na[k].x);
+                const bool c0 = q_go_right<MS, NARROW, EXCH>(q_xread<LDSX, NARROW>(gx, na[k].x, pos[k]), na[k].x);
                 const uint32_t n1 = c0 ? na[k].z : na[k].y;
-                const bool c1 = q_go_right<MS, NARROW>(q_xread<LDSX, NARROW>(gx, n1, pos[k]), n1);
+                const bool c1 = q_go_right<MS, NARROW, EXCH>(q_xread<LDSX, NARROW>(gx, n1, pos[k]), n1);
                 const uint32_t lo = c0 ? nb[k].z : nb[k].x, hi = c0 ? nb[k].w : nb[k].y;
                 v[k] = __uint_as_float(c1 ? hi : lo);
                 if (WRITE_LEAF) {
@@ -224,7 +224,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                     }
     #pragma unroll
                     for (int k = 0; k < K; ++k) {
-                        const uint64_t cm = q_right_mask<MS, NARROW>(xc[k], node[k]);
+                        const uint64_t cm = q_right_mask<MS, NARROW, EXCH>(xc[k], node[k]);
                         i[k] = q_descend(i[k], cm);
                         node[k] = __builtin_amdgcn_inverse_ballot_w64(cm) ? pr[k].y : pr[k].x;
                     }
@@ -232,7 +232,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
     #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     const uint32_t xc = q_xread<LDSX, NARROW>(gx, node[k], pos[k]);
-                    i[k] = q_descend(i[k], q_right_mask<MS, NARROW>(xc, node[k]));
+                    i[k] = q_descend(i[k], q_right_mask<MS, NARROW, EXCH>(xc, node[k]));
                 }
             }
             uint32_t bsel[K];
@@ -244,7 +244,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                     for (int l = top_levels; l < depth - 2; ++l) {
                         const uint32_t n = tree[idx];
                         const uint32_t xc = q_xread<LDSX, NARROW>(gx, n, pos[k]);
-                        idx = 2u * idx + 1u + (q_go_right<MS, NARROW>(xc, n) ? 1u : 0u);
+                        idx = 2u * idx + 1u + (q_go_right<MS, NARROW, EXCH>(xc, n) ? 1u : 0u);
                     }
                 }
                 bsel[k] = idx - first_block_node;
@@ -532,9 +532,10 @@ static hipError_t q_allow(long long lds)
     if (e != hipSuccess) return e;
     e = allow_max_lds(reinterpret_cast<const void *>(&qring_kernel<NWALK, true, true>), (int)lds);
     if (e != hipSuccess || NWALK != 15) return e;
-    e = allow_max_lds(reinterpret_cast<const void *>(&qring_kernel<15, false, true, true>), (int)lds);
-    if (e != hipSuccess) return e;
-    return allow_max_lds(reinterpret_cast<const void *>(&qring_kernel<15, true, true, true>), (int)lds);
+    for (const void *k : {(const void *)&qring_kernel<15, false, true, true>, (const void *)&qring_kernel<15, true, true, true>,
+                          (const void *)&qring_kernel<15, false, true, true, true>, (const void *)&qring_kernel<15, true, true, true, true>})
+        if ((e = allow_max_lds(k, (int)lds)) != hipSuccess) return e;
+    return hipSuccess;
 }
 
 // Builds one tree group [lo, hi).  Returns TAHOE_OK with *too_many = the largest per-feature count when that
@@ -550,7 +551,7 @@ static tahoe_status build_group(tahoe_forest *f, const std::vector<InnerNode> &h
     std::vector<std::vector<float>> tab((size_t)cols);
     for (size_t i = lo * n_inner; i < hi * n_inner; ++i) {
         if (!h_real[i] || std::isnan(h_inner[i].thr)) continue;
-        tab[h_inner[i].meta & 0x7fffffffu].push_back(h_inner[i].thr);
+        tab[h_inner[i].meta & kMetaFidMask].push_back(h_inner[i].thr);
     }
     parallel_for((size_t)cols, 4, [&tab](size_t c_lo, size_t c_hi) {  // features are independent
         for (size_t c = c_lo; c < c_hi; ++c) {
@@ -568,7 +569,7 @@ static tahoe_status build_group(tahoe_forest *f, const std::vector<InnerNode> &h
     // ---- node codes ----
     auto encode = [&](const InnerNode &n, bool real) -> uint32_t {
         if (!real) return 0u;  // padding below a leaf: both children carry the same value
-        const uint32_t fid = n.meta & 0x7fffffffu, dl = n.meta >> 31;
+        const uint32_t fid = n.meta & kMetaFidMask, dl = n.meta >> 31, ex = (n.meta & kMetaExchange) ? 1u : 0u;
         uint32_t code;
         if (std::isnan(n.thr))
             code = 0xFFFFu;  // x >= NaN is never true; a missing x still follows def_left
@@ -576,7 +577,7 @@ static tahoe_status build_group(tahoe_forest *f, const std::vector<InnerNode> &h
             const auto &v = tab[fid];
             code = (uint32_t)(std::lower_bound(v.begin(), v.end(), n.thr) - v.begin()) + 1u;
         }
-        return q->narrow ? (code << 16) | (fid << 8) | dl : code | (fid << 16) | (dl << 31);
+        return q->narrow ? (code << 16) | (fid << 8) | (ex << 7) | dl : code | (fid << 16) | (dl << 31);
     };
     const size_t Tg = hi - lo;
     g.tree_lo = (int)lo;
@@ -651,6 +652,10 @@ tahoe_status qring_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner,
         const char *e = getenv("TAHOE_QRING_NARROW");  // experiments: 0 keeps the general node layout
         q->narrow = cols <= 256 && qring_walkers(f) == 15 && qring_lds_tile(f) && !(e && atoi(e) == 0);
     }
+    if (f->relayout && !q->narrow) {  // only the NARROW node word has room for the exchange bit: the strategy steps aside
+        qring_destroy(f);
+        return TAHOE_OK;
+    }
     // ---- cut the forest into tree groups whose features each see <= kQMaxTable distinct thresholds ----
     // G groups of (nearly) equal size, G as small as the busiest feature allows.  First guess from the node counts per
     // feature (an upper bound of its distinct thresholds), then G grows until every group fits; trees that differ
@@ -659,7 +664,7 @@ tahoe_status qring_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner,
     {
         std::vector<size_t> per_feature((size_t)cols, 0);
         for (size_t i = 0; i < T * f->n_inner; ++i)
-            if (h_real[i] && !std::isnan(h_inner[i].thr)) ++per_feature[h_inner[i].meta & 0x7fffffffu];
+            if (h_real[i] && !std::isnan(h_inner[i].thr)) ++per_feature[h_inner[i].meta & kMetaFidMask];
         const size_t most = *std::max_element(per_feature.begin(), per_feature.end());
         if (most > (size_t)kQMaxTable + kQMaxTable / 2) G = (most + kQMaxTable - 1) / kQMaxTable;  // below 1.5x: try one group first
     }
@@ -749,7 +754,7 @@ tahoe_status qring_reserve(tahoe_forest *f, size_t rows)
     return TAHOE_OK;
 }
 
-template <int NWALK, bool LDSX = true, bool NARROW = false>
+template <int NWALK, bool LDSX = true, bool NARROW = false, bool EXCH = false>
 static void q_launch(tahoe_forest *f, const tahoe_qgroup &g, float *sums, const float *sums_in, uint32_t *leaf_out,
                      size_t rows, hipStream_t stream, int cshift)
 {
@@ -758,11 +763,11 @@ static void q_launch(tahoe_forest *f, const tahoe_qgroup &g, float *sums, const 
     const int lds = (int)qring_lds_for(f, NWALK, LDSX);
     const uint32_t *leaf_orig = f->leaf_orig + (size_t)g.tree_lo * f->n_leaf;
     if (leaf_out)
-        hipLaunchKernelGGL((qring_kernel<NWALK, true, LDSX, NARROW>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, g.top,
+        hipLaunchKernelGGL((qring_kernel<NWALK, true, LDSX, NARROW, EXCH>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, g.top,
                            g.blocks, g.qinner, leaf_orig, sums, leaf_out, rows, f->p.num_cols, g.num_trees, f->depth,
                            q->top_levels, q->top_stride, q->chunk_flags, f->error_flag, sums_in, g.tree_lo, f->p.num_trees, cshift);
     else
-        hipLaunchKernelGGL((qring_kernel<NWALK, false, LDSX, NARROW>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, g.top,
+        hipLaunchKernelGGL((qring_kernel<NWALK, false, LDSX, NARROW, EXCH>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, g.top,
                            g.blocks, g.qinner, leaf_orig, sums, leaf_out, rows, f->p.num_cols, g.num_trees, f->depth,
                            q->top_levels, q->top_stride, q->chunk_flags, f->error_flag, sums_in, g.tree_lo, f->p.num_trees, cshift);
 }
@@ -824,7 +829,9 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
         else
         switch (nwalk) {
             case 15:
-                if (q->narrow)
+                if (q->narrow && f->relayout)
+                    q_launch<15, true, true, true>(f, g, sums, sums_in, leaf_out, rows, stream, cshift);
+                else if (q->narrow)
                     q_launch<15, true, true>(f, g, sums, sums_in, leaf_out, rows, stream, cshift);
                 else
                     q_launch<15>(f, g, sums, sums_in, leaf_out, rows, stream, cshift);

@@ -103,22 +103,29 @@ inline hipError_t q_upload(T **dst, const T *src, size_t count, size_t *total)
 // predicate of v_cndmask / v_addc (hipcc's ?: form materialises both booleans in VGPRs: 6 more VALU).
 // MS = false is the fast path for row chunks in which the quantise pass met no missing value (it
 // reports that per chunk): the rule is then the single compare.
-// NARROW (num_cols <= 256): node = code << 16 | fid << 8 | def_left, so that the feature column's LDS offset
+// NARROW (num_cols <= 256): node = code << 16 | fid << 8 | exchange << 7 | def_left, so that the feature column's LDS offset
 // (fid * 256) is a bit field of the node word and one v_bfi forms the read address (q_xread).
-template <bool MS, bool NARROW>
+// EX (NARROW only; probability-guided re-layout): bit 7 of the node word marks a node whose children are stored swapped;
+// the condition is inverted there.  One more v_cmp (the sign of byte 0) and one s_xor per step.
+template <bool MS, bool NARROW, bool EX = false>
 __device__ __forceinline__ uint64_t q_right_mask(uint32_t xc, uint32_t node)
 {
+    static_assert(!EX || NARROW, "the exchange bit lives in the NARROW node word");
     const uint64_t ge = __builtin_amdgcn_uicmp(xc, NARROW ? node >> 16 : node & 0xFFFFu, 35 /* ICMP_UGE */);
-    if (!MS) return ge;
-    const uint64_t ms = __builtin_amdgcn_uicmp(xc, kCodeMissing, 32 /* ICMP_EQ */);
-    const uint64_t ndl = NARROW ? __builtin_amdgcn_uicmp(node & 0xFFu, 0u, 32 /* ICMP_EQ: def_left clear */)
-                                : __builtin_amdgcn_sicmp((int)node, -1, 38 /* ICMP_SGT: bit 31 (def_left) clear */);
-    return (ge & ~ms) | (ms & ndl);
+    uint64_t right = ge;
+    if (MS) {
+        const uint64_t ms = __builtin_amdgcn_uicmp(xc, kCodeMissing, 32 /* ICMP_EQ */);
+        const uint64_t ndl = NARROW ? __builtin_amdgcn_uicmp(node & 0x1u, 0u, 32 /* ICMP_EQ: def_left clear */)
+                                    : __builtin_amdgcn_sicmp((int)node, -1, 38 /* ICMP_SGT: bit 31 (def_left) clear */);
+        right = (ge & ~ms) | (ms & ndl);
+    }
+    if (EX) right ^= __builtin_amdgcn_sicmp((int)(int8_t)(node & 0xFFu), 0, 40 /* ICMP_SLT: bit 7 (exchange) set */);
+    return right;
 }
-template <bool MS, bool NARROW>
+template <bool MS, bool NARROW, bool EX = false>
 __device__ __forceinline__ bool q_go_right(uint32_t xc, uint32_t node)
 {
-    return __builtin_amdgcn_inverse_ballot_w64(q_right_mask<MS, NARROW>(xc, node));
+    return __builtin_amdgcn_inverse_ballot_w64(q_right_mask<MS, NARROW, EX>(xc, node));
 }
 // i <- 2i + (lane's bit of mask): one v_addc with the mask as carry-in
 __device__ __forceinline__ uint32_t q_descend(uint32_t i, uint64_t right_mask)

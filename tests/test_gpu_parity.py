@@ -300,6 +300,58 @@ def test_predict_accumulate_continues_the_sum_on_every_strategy(env):
         assert np.array_equal(bits(got.cpu().numpy()), bits(want)), s
 
 
+def test_probability_relayout_keeps_every_result(env):
+    """SURVEY 8f N3 (Struct.h:1775-1825): with TAHOE_CREATE_PROB_RELAYOUT the subtrees are ordered by dense_node_t.weight and
+    marked nodes invert their condition; leaf indices (original heap numbering) and float32 sums must not change."""
+    ta, oracle, torch = env
+    cases = [(60, 8, 32, 1500, 0.1, True), (40, 12, 256, 700, 0.0, True), (25, 5, 7, 300, 0.3, False), (12, 2, 3, 200, 0.0, False),
+             (30, 7, 600, 257, 0.05, True), (3, 0, 2, 10, 0.0, False), (5, 1, 4, 65, 0.0, False)]
+    for (T, D, C, R, lp, prob_weights) in cases:
+        nodes = ta.synth_forest(T, D, C, seed=51, leaf_prob=lp)  # weight = a random number per node
+        if prob_weights:
+            ta.capi.set_probability_weights(nodes, T, D)          # weight = probability of reaching the node
+        data = ta.synth_data(R, C, seed=52, missing_prob=0.05, missing=MISSING, nan_prob=0.01)
+        want, want_leaf = oracle.predict(nodes, T, D, data, MISSING, want_leaf=True)
+        x = torch.from_numpy(data).cuda()
+        forest = ta.Forest(nodes, T, D, C, missing=MISSING, relayout=True)
+        info = forest.info()
+        assert info.relayout == 1 and (D == 0 or info.relayout_swaps > 0)
+        assert info.tile_rows == 0 and info.ring_rows == 0  # the float32 block views have no room for the exchange bit
+        if C <= 256:
+            assert info.qring_walkers == 15
+        else:
+            assert info.qring_walkers == 0
+            with pytest.raises(ta.TahoeError):
+                forest.set_strategy(ta.STRATEGY_QRING)
+        with pytest.raises(ta.TahoeError):
+            forest.set_strategy(ta.STRATEGY_TILEBLOCK)
+        strategies = [ta.STRATEGY_DIRECT, ta.STRATEGY_AUTO] + ([ta.STRATEGY_ROWTILE] if info.lds_bytes_per_block > 0 else []) + (
+            [ta.STRATEGY_QRING] if info.qring_walkers > 0 else [])
+        for s in strategies:
+            forest.set_strategy(s)
+            leaf, sums = forest.predict_leaf_idx(x)
+            raw = forest.predict_raw(x)
+            forest.check()
+            assert np.array_equal(bits(leaf.cpu().numpy()), want_leaf), (T, D, C, s)
+            assert np.array_equal(bits(sums.cpu().numpy()), bits(want)), (T, D, C, s)
+            assert np.array_equal(bits(raw.cpu().numpy()), bits(want)), (T, D, C, s)
+        # without missing values the walk kernel takes its fast path (MS = false): check that one too
+        clean = ta.synth_data(R, C, seed=53)
+        w2, _ = oracle.predict(nodes, T, D, clean, MISSING)
+        forest.set_strategy(ta.STRATEGY_AUTO)
+        assert np.array_equal(bits(forest.predict_raw(torch.from_numpy(clean).cuda()).cpu().numpy()), bits(w2))
+        forest.close()
+    # the likelier child is the left one afterwards: with probability weights, rows concentrate on low leaf positions
+    T, D, C, R = 8, 10, 16, 4000
+    nodes = ta.capi.set_probability_weights(ta.synth_forest(T, D, C, seed=61), T, D)
+    data = ta.synth_data(R, C, seed=62)
+    plain, relaid = ta.Forest(nodes, T, D, C, missing=MISSING), ta.Forest(nodes, T, D, C, missing=MISSING, relayout=True)
+    x = torch.from_numpy(data).cuda()
+    a, _ = plain.predict_leaf_idx(x, want_sums=False)
+    b, _ = relaid.predict_leaf_idx(x, want_sums=False)
+    assert np.array_equal(a.cpu().numpy(), b.cpu().numpy())  # same leaves, in the original numbering
+
+
 # ---- the rank-quantised path (QRING): exactness at the edges of the float order ----
 
 def test_quantised_threshold_edge_values(env):
