@@ -1302,7 +1302,7 @@ tahoe_status tahoe_forest_get_info(const tahoe_forest *f, tahoe_forest_info *inf
     info->qring_groups = qring_groups(f);
     info->ring_rows = tilering_rows(f);
     info->tilering_lds_bytes = info->ring_rows ? (int)tilering_lds_bytes(f, info->ring_rows) : 0;
-    info->qring_tile_rows = info->qring_walkers == 0 ? 0 : qwide_rows(f) ? qwide_rows(f) : qring_lds_tile(f) ? 128 : 0;
+    info->qring_tile_rows = info->qring_walkers == 0 ? 0 : qwide_rows(f) ? qwide_rows(f) : qring_regions(f) ? 192 : qring_lds_tile(f) ? 128 : 0;
     info->relayout = f->relayout ? 1 : 0;
     info->relayout_swaps = f->relayout_swaps;
     return TAHOE_OK;

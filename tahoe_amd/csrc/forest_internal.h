@@ -77,6 +77,7 @@ struct tahoe_forest {
     size_t relayout_swaps = 0;
     int knob_tile_rows = 0;
     int knob_qring_walkers = 0;
+    int knob_qring_chains = 0;  // TAHOE_QRING_CHAINS = 2 / 3: force the tile form of QRING's region layout
     // Profiling: one hipEvent pair per traversal launch, read back after the stream has drained.
     bool profiling = false;
     std::vector<hipEvent_t> ev_start, ev_mid, ev_stop;  // mid: between a pre-pass kernel and the walk kernel
@@ -132,6 +133,7 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
 tahoe_status qring_reserve(tahoe_forest *f, size_t rows);
 int qwide_rows(const tahoe_forest *f);   // rows per tile of the wide-row form; 0 = not used
 bool qring_lds_tile(const tahoe_forest *f);
+bool qring_regions(const tahoe_forest *f);  // region form: tiles of 192 (or 128) rows as 64-row regions
 int qring_groups(const tahoe_forest *f);  // tree groups with separate quantisation (1 for most forests)
 
 // sparse forests (sparse.hip)

@@ -40,9 +40,14 @@
 namespace tahoe {
 
 // ------------------------------------------------------------------------------------------------
-// (2) the walk.  Dynamic LDS: tile [cols][128] u16 | NWALK slots of (4 << L) bytes | ring [16][128] f32 |
-// ready[16] | consumed.
-template <int NWALK, bool WRITE_LEAF, bool LDSX, bool NARROW = false, bool EXCH = false>
+// (2) the walk.  Dynamic LDS: tile [cols][128] u16 | NWALK slots of (4 << L) bytes | ring [RING][64 K] f32 |
+// ready[RING] | consumed.
+// REG (the form K3 runs; NARROW node words with fid << 7, num_cols <= 256): the tile is K regions of 64 rows, region k =
+// [fid][64] u16 at LDS address k * 32 KiB (so that the column offset fid * 128 and the region base never share a bit and
+// one v_bfi forms the read address), chain k of a lane walks row 64 k + lane.  K = 3: a top staged once serves 192 rows
+// (profiles/r02/tiles_experiment.json: almost half of a tile's time does not depend on its rows) with 13 walkers and a
+// ring of 15; K = 2 (15 walkers, ring of 24) for batches that fill the chip better with 128-row tiles.
+template <int NWALK, bool WRITE_LEAF, bool LDSX, bool NARROW = false, bool EXCH = false, int K = 2, bool REG = false, int RING = kQRing>
 __global__ void __launch_bounds__((NWALK + 1) * 64)
     qring_kernel(const uint16_t *__restrict__ xq, const uint32_t *__restrict__ top, const uint4 *__restrict__ blocks,
                  const uint32_t *__restrict__ qinner, const uint32_t *__restrict__ leaf_orig, float *__restrict__ sums,
@@ -50,7 +55,11 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                  int top_stride, const uint32_t *__restrict__ chunk_flags, int *__restrict__ error_flag,
                  const float *sums_in, int tree_base, int total_trees, int cshift)
 {
-    constexpr int K = kQRows / 64;  // two 64-row chains per walker lane
+    static_assert(REG || K == kQRows / 64, "the 128-slot column layout holds exactly two chains");
+    static_assert(!REG || (LDSX && NARROW && !EXCH), "regions are a form of the NARROW LDS tile");
+    static_assert(RING > NWALK && RING >= 2 * kQBatch, "ring too small");
+    constexpr int TR = 64 * K;             // rows per tile
+    constexpr int CS = REG ? 7 : 8;        // log2 of a feature column's bytes
     constexpr int NT = (NWALK + 1) * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -59,13 +68,13 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
     constexpr int slot_bytes = kQSlotBytes;  // fixed 4 KiB slot (2^10 u32): no size-dependent branches in the loop
 
     uint16_t *tile = reinterpret_cast<uint16_t *>(smem);  // LDSX only
-    unsigned char *slots = smem + (LDSX ? (size_t)cols * kQRows * sizeof(uint16_t) : 0);
-    const unsigned char *gx = reinterpret_cast<const unsigned char *>(xq + (size_t)blockIdx.x * ((size_t)cols * kQRows));
+    unsigned char *slots = smem + (REG ? (size_t)K * kRegBytes : LDSX ? (size_t)cols * TR * sizeof(uint16_t) : 0);
+    const unsigned char *gx = reinterpret_cast<const unsigned char *>(xq + (size_t)blockIdx.x * ((size_t)cols * TR));
     float *ring_vals = reinterpret_cast<float *>(slots + (size_t)NWALK * slot_bytes);
-    uint32_t *ring_ready = reinterpret_cast<uint32_t *>(ring_vals + kQRing * kQRows);
-    uint32_t *consumed = ring_ready + kQRing;
+    uint32_t *ring_ready = reinterpret_cast<uint32_t *>(ring_vals + RING * TR);
+    uint32_t *consumed = ring_ready + RING;
 
-    const size_t row0 = (size_t)blockIdx.x * kQRows;
+    const size_t row0 = (size_t)blockIdx.x * TR;
     if (LDSX && NARROW && (uint32_t)reinterpret_cast<uintptr_t>(tile) != 0u) {
         // q_xread's v_bfi needs the tile at LDS address 0 (true while the kernel has no static LDS)
         if (tid == 0) atomicOr(error_flag, 2);
@@ -73,14 +82,21 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
     }
 
     // ---- stage the quantised tile (already in LDS order): straight 16-byte copies ----
-    if (LDSX) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(xq + (size_t)blockIdx.x * ((size_t)cols * kQRows));
+    if (REG) {  // K consecutive regions of the workspace, each to its 32-KiB-aligned place
+        const int n16 = cols * kRegRows * 2 / 16;  // 16-byte pieces of a region
+        for (int k = 0; k < K; ++k) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(xq + ((size_t)blockIdx.x * K + k) * ((size_t)cols * kRegRows));
+            uint4 *dst = reinterpret_cast<uint4 *>(smem + (size_t)k * kRegBytes);
+            for (int e = tid; e < n16; e += NT) dst[e] = src[e];
+        }
+    } else if (LDSX) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(xq + (size_t)blockIdx.x * ((size_t)cols * TR));
         uint4 *dst = reinterpret_cast<uint4 *>(tile);
-        const int n16 = cols * kQRows * 2 / 16;
+        const int n16 = cols * TR * 2 / 16;
         for (int e = tid; e < n16; e += NT) dst[e] = src[e];
     }
-    if (tid < kQRing) ring_ready[tid] = 0u;
-    if (tid == kQRing) *consumed = 0u;
+    if (tid < RING) ring_ready[tid] = 0u;
+    if (tid == RING) *consumed = 0u;
 
     if (wave == NWALK) {
         // ================= consumer: ordered accumulation =================
@@ -96,7 +112,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
             const int nb = min(kQBatch, num_trees - t0);
             int spins = 0;
             for (;;) {
-                const bool ok = lane >= nb || lds_flag_load(&ring_ready[(t0 + lane) % kQRing]) == (uint32_t)(t0 + lane + 1);
+                const bool ok = lane >= nb || lds_flag_load(&ring_ready[(t0 + lane) % RING]) == (uint32_t)(t0 + lane + 1);
                 if (__ballot(ok) == ~0ull) break;
                 if (++spins > kQSpinLimit) {
                     dead = true;
@@ -107,9 +123,9 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
             if (dead) break;
             asm volatile("" ::: "memory");  // the values are read after the flags
             for (int j = 0; j < nb; ++j) {
-                const int e = (t0 + j) % kQRing;
+                const int e = (t0 + j) % RING;
 #pragma unroll
-                for (int k = 0; k < K; ++k) sum[k] += ring_vals[e * kQRows + k * 64 + lane];  // tree order
+                for (int k = 0; k < K; ++k) sum[k] += ring_vals[e * TR + k * 64 + lane];  // tree order
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane == 0) lds_flag_store(consumed, (uint32_t)(t0 + nb));
@@ -159,7 +175,8 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
         uint32_t pos[K];  // byte position of this lane's row inside a 256-byte feature column, per chain
     #pragma unroll
         for (int k = 0; k < K; ++k)  // low 32 bits of a generic LDS pointer = the LDS byte address
-            pos[k] = (LDSX ? (uint32_t)reinterpret_cast<uintptr_t>(tile) : 0u) + 2u * (uint32_t)qrow_pos(k * 64 + lane);
+            pos[k] = REG ? (uint32_t)(k * kRegBytes) + 2u * (uint32_t)qreg_pos(lane)
+                         : (LDSX ? (uint32_t)reinterpret_cast<uintptr_t>(tile) : 0u) + 2u * (uint32_t)qrow_pos(k * 64 + lane);
         const size_t n_inner = ((size_t)1 << depth) - 1;
         const uint32_t n_blocks = 1u << (depth - 2);
         const uint32_t first_block_node = n_blocks - 1;
@@ -170,9 +187,9 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
             for (int k = 0; k < K; ++k) {
                 // two dependent steps (the kernel is VALU-bound: this is ~half the instructions of evaluating
                 // both second-level nodes)
-                const bool c0 = q_go_right<MS, NARROW, EXCH>(q_xread<LDSX, NARROW>(gx, na[k].x, pos[k]), na[k].x);
+                const bool c0 = q_go_right<MS, NARROW, EXCH>(q_xread<LDSX, NARROW, CS>(gx, na[k].x, pos[k]), na[k].x);
                 const uint32_t n1 = c0 ? na[k].z : na[k].y;
-                const bool c1 = q_go_right<MS, NARROW, EXCH>(q_xread<LDSX, NARROW>(gx, n1, pos[k]), n1);
+                const bool c1 = q_go_right<MS, NARROW, EXCH>(q_xread<LDSX, NARROW, CS>(gx, n1, pos[k]), n1);
                 const uint32_t lo = c0 ? nb[k].z : nb[k].x, hi = c0 ? nb[k].w : nb[k].y;
                 v[k] = __uint_as_float(c1 ? hi : lo);
                 if (WRITE_LEAF) {
@@ -182,9 +199,9 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                             leaf_orig[(size_t)t * ((size_t)n_blocks * 4) + (size_t)bs[k] * 4 + 2 * (c0 ? 1 : 0) + (c1 ? 1 : 0)];
                 }
             }
-            if (t >= kQRing) {  // ring entry still in use by tree t - kQRing?
+            if (t >= RING) {  // ring entry still in use by tree t - RING?
                 int spins = 0;
-                while (lds_flag_load(consumed) < (uint32_t)(t - kQRing + 1)) {
+                while (lds_flag_load(consumed) < (uint32_t)(t - RING + 1)) {
                     if (++spins > kQSpinLimit) {
                         dead = true;
                         break;
@@ -192,9 +209,9 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                     __builtin_amdgcn_s_sleep(TAHOE_WALK_SLEEP);
                 }
             }
-            const int e = t % kQRing;
+            const int e = t % RING;
     #pragma unroll
-            for (int k = 0; k < K; ++k) ring_vals[e * kQRows + k * 64 + lane] = v[k];
+            for (int k = 0; k < K; ++k) ring_vals[e * TR + k * 64 + lane] = v[k];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // values before the flag (in-order LDS)
             if (lane == 0) lds_flag_store(&ring_ready[e], (uint32_t)(t + 1));
         };
@@ -219,7 +236,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                     uint2 pr[K];
     #pragma unroll
                     for (int k = 0; k < K; ++k) {
-                        xc[k] = q_xread<LDSX, NARROW>(gx, node[k], pos[k]);
+                        xc[k] = q_xread<LDSX, NARROW, CS>(gx, node[k], pos[k]);
                         pr[k] = *reinterpret_cast<const uint2 *>(&slot[2 * i[k]]);  // children 2i, 2i+1
                     }
     #pragma unroll
@@ -231,7 +248,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                 }
     #pragma unroll
                 for (int k = 0; k < K; ++k) {
-                    const uint32_t xc = q_xread<LDSX, NARROW>(gx, node[k], pos[k]);
+                    const uint32_t xc = q_xread<LDSX, NARROW, CS>(gx, node[k], pos[k]);
                     i[k] = q_descend(i[k], q_right_mask<MS, NARROW, EXCH>(xc, node[k]));
                 }
             }
@@ -243,7 +260,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                     const uint32_t *tree = qinner + (size_t)t * n_inner;
                     for (int l = top_levels; l < depth - 2; ++l) {
                         const uint32_t n = tree[idx];
-                        const uint32_t xc = q_xread<LDSX, NARROW>(gx, n, pos[k]);
+                        const uint32_t xc = q_xread<LDSX, NARROW, CS>(gx, n, pos[k]);
                         idx = 2u * idx + 1u + (q_go_right<MS, NARROW, EXCH>(xc, n) ? 1u : 0u);
                     }
                 }
@@ -265,8 +282,9 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
         }
         if (t_p >= 0 && !dead) finish(t_p, na_p, nb_p, bsel_p);
     };
-    // chunk_flags[c] != 0 <=> the quantise pass met a missing value in rows [c, c+1) << cshift
-    if (chunk_flags[row0 >> cshift] != 0)
+    // chunk_flags[c] != 0 <=> the quantise pass met a missing value in rows [c, c+1) << cshift; a 192-row tile can
+    // straddle two chunks (a chunk is at least 512 rows)
+    if ((chunk_flags[row0 >> cshift] | chunk_flags[(min(rows, row0 + TR) - 1) >> cshift]) != 0)
         run(std::true_type{});
     else
         run(std::false_type{});
@@ -467,6 +485,12 @@ __global__ void __launch_bounds__(16 * 64)
 }
 
 // ------------------------------------------------------------------------------------------------
+// LDS of the region form: K regions of 32 KiB, walker slots, ring
+static long long qreg_lds_for(int k, int nwalk, int ring)
+{
+    return (long long)k * kRegBytes + (long long)nwalk * kQSlotBytes + (long long)ring * k * kRegRows * 4 + (ring + 1) * 4LL;
+}
+
 static long long qring_lds_for(const tahoe_forest *f, int nwalk, bool lds_tile = true)
 {
     return (lds_tile ? (long long)f->p.num_cols * kQRows * 2 : 0) + (long long)nwalk * kQSlotBytes +
@@ -521,6 +545,7 @@ int qring_walkers(const tahoe_forest *f)
 
 long long qring_lds_bytes(const tahoe_forest *f)
 {
+    if (f->q && f->q->reg) return qreg_lds_for(3, kReg3Walkers, kReg3Ring);
     const int n = qring_walkers(f);
     return n ? qring_lds_for(f, n, qring_lds_tile(f)) : 0;
 }
@@ -533,7 +558,10 @@ static hipError_t q_allow(long long lds)
     e = allow_max_lds(reinterpret_cast<const void *>(&qring_kernel<NWALK, true, true>), (int)lds);
     if (e != hipSuccess || NWALK != 15) return e;
     for (const void *k : {(const void *)&qring_kernel<15, false, true, true>, (const void *)&qring_kernel<15, true, true, true>,
-                          (const void *)&qring_kernel<15, false, true, true, true>, (const void *)&qring_kernel<15, true, true, true, true>})
+                          (const void *)&qring_kernel<15, false, true, true, true>, (const void *)&qring_kernel<15, true, true, true, true>,
+                          (const void *)&qring_kernel<15, false, true, true, false, 2, true>, (const void *)&qring_kernel<15, true, true, true, false, 2, true>,
+                          (const void *)&qring_kernel<kReg3Walkers, false, true, true, false, 3, true, kReg3Ring>,
+                          (const void *)&qring_kernel<kReg3Walkers, true, true, true, false, 3, true, kReg3Ring>})
         if ((e = allow_max_lds(k, (int)lds)) != hipSuccess) return e;
     return hipSuccess;
 }
@@ -577,6 +605,7 @@ static tahoe_status build_group(tahoe_forest *f, const std::vector<InnerNode> &h
             const auto &v = tab[fid];
             code = (uint32_t)(std::lower_bound(v.begin(), v.end(), n.thr) - v.begin()) + 1u;
         }
+        if (q->reg) return (code << 16) | (fid << 7) | dl;  // region form: the column offset fid * 128 is a bit field of the node
         return q->narrow ? (code << 16) | (fid << 8) | (ex << 7) | dl : code | (fid << 16) | (dl << 31);
     };
     const size_t Tg = hi - lo;
@@ -651,6 +680,11 @@ tahoe_status qring_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner,
     {
         const char *e = getenv("TAHOE_QRING_NARROW");  // experiments: 0 keeps the general node layout
         q->narrow = cols <= 256 && qring_walkers(f) == 15 && qring_lds_tile(f) && !(e && atoi(e) == 0);
+    }
+    {
+        const char *e = getenv("TAHOE_QRING_REGIONS");  // experiments: 0 keeps the 128-slot column layout
+        q->reg = q->narrow && !f->relayout && qreg_lds_for(3, kReg3Walkers, kReg3Ring) <= f->lds_limit && !(e && atoi(e) == 0);
+        if (const char *k = getenv("TAHOE_QRING_CHAINS")) f->knob_qring_chains = atoi(k);  // 2 / 3: force the tile form
     }
     if (f->relayout && !q->narrow) {  // only the NARROW node word has room for the exchange bit: the strategy steps aside
         qring_destroy(f);
@@ -729,13 +763,16 @@ void qring_destroy(tahoe_forest *f)
 }
 
 int qring_groups(const tahoe_forest *f) { return f->q ? (int)f->q->groups.size() : 0; }
+bool qring_regions(const tahoe_forest *f) { return f->q && f->q->reg; }
 
 // The quantised copy of the batch lives in a grow-only workspace owned by the handle.
 tahoe_status qring_reserve(tahoe_forest *f, size_t rows)
 {
     tahoe_qstate *q = f->q;
     if (!q) return TAHOE_OK;  // no quantised form on this handle
-    const size_t tiles = (rows + kQRows - 1) / kQRows;
+    size_t tiles = (rows + kQRows - 1) / kQRows;
+    // region form: a walk tile reads two or three whole 64-row regions -> room for the last tile to read past the batch
+    if (q->reg) tiles = ((rows + kRegRows - 1) / kRegRows + 2 + 1) / 2;
     if (tiles * kQRows <= q->xq_rows) return TAHOE_OK;
     if (q->xq) {
         TAHOE_HIP_TRY(hipDeviceSynchronize());  // a previous launch may still read the old buffer
@@ -754,20 +791,20 @@ tahoe_status qring_reserve(tahoe_forest *f, size_t rows)
     return TAHOE_OK;
 }
 
-template <int NWALK, bool LDSX = true, bool NARROW = false, bool EXCH = false>
+template <int NWALK, bool LDSX = true, bool NARROW = false, bool EXCH = false, int K = 2, bool REG = false, int RING = kQRing>
 static void q_launch(tahoe_forest *f, const tahoe_qgroup &g, float *sums, const float *sums_in, uint32_t *leaf_out,
                      size_t rows, hipStream_t stream, int cshift)
 {
     tahoe_qstate *q = f->q;
-    const unsigned grid = (unsigned)((rows + kQRows - 1) / kQRows);
-    const int lds = (int)qring_lds_for(f, NWALK, LDSX);
+    const unsigned grid = (unsigned)((rows + 64 * K - 1) / (64 * K));
+    const int lds = REG ? (int)qreg_lds_for(K, NWALK, RING) : (int)qring_lds_for(f, NWALK, LDSX);
     const uint32_t *leaf_orig = f->leaf_orig + (size_t)g.tree_lo * f->n_leaf;
     if (leaf_out)
-        hipLaunchKernelGGL((qring_kernel<NWALK, true, LDSX, NARROW, EXCH>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, g.top,
+        hipLaunchKernelGGL((qring_kernel<NWALK, true, LDSX, NARROW, EXCH, K, REG, RING>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, g.top,
                            g.blocks, g.qinner, leaf_orig, sums, leaf_out, rows, f->p.num_cols, g.num_trees, f->depth,
                            q->top_levels, q->top_stride, q->chunk_flags, f->error_flag, sums_in, g.tree_lo, f->p.num_trees, cshift);
     else
-        hipLaunchKernelGGL((qring_kernel<NWALK, false, LDSX, NARROW, EXCH>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, g.top,
+        hipLaunchKernelGGL((qring_kernel<NWALK, false, LDSX, NARROW, EXCH, K, REG, RING>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, g.top,
                            g.blocks, g.qinner, leaf_orig, sums, leaf_out, rows, f->p.num_cols, g.num_trees, f->depth,
                            q->top_levels, q->top_stride, q->chunk_flags, f->error_flag, sums_in, g.tree_lo, f->p.num_trees, cshift);
 }
@@ -804,7 +841,18 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
     tahoe_status s = qring_reserve(f, rows);  // no-op unless this batch is larger than any before
     if (s != TAHOE_OK) return s;
     const int wide = qwide_rows(f);  // 0: 128-row tiles; else rows per tile of the wide-row form
-    const int trs = wide == 64 ? 6 : wide == 32 ? 5 : wide == 16 ? 4 : 7;
+    const int trs = q->reg ? 6 : wide == 64 ? 6 : wide == 32 ? 5 : wide == 16 ? 4 : 7;
+    // Region form: 192-row tiles (three chains, 13 walkers) unless 128-row tiles (two chains, 15 walkers) need less time.
+    // Measured on K3 (profiles/r02/tiles_experiment.json): a 192-row tile takes 1.44 x a 128-row tile, i.e. 0.96 of the time
+    // per row -- but 10 k rows run as 79 tiles of 128 on 79 CUs rather than 53 of 192, and 125 k rows as 4 waves of 128-row
+    // tiles (4.0) rather than 3 waves of 192-row tiles (4.3).
+    int chains = 2;
+    if (q->reg) {
+        const size_t cus = (size_t)std::max(f->num_cus, 1);
+        const size_t w2 = ((rows + 127) / 128 + cus - 1) / cus, w3 = ((rows + 191) / 192 + cus - 1) / cus;
+        chains = 100 * w2 <= 144 * w3 ? 2 : 3;
+        if (f->knob_qring_chains == 2 || f->knob_qring_chains == 3) chains = f->knob_qring_chains;
+    }
     if ((rows + (wide ? wide : kQRows) - 1) / (wide ? wide : kQRows) > 0x7fffffffu)
         return fail(TAHOE_ERR_INVALID_ARG, "too many rows for one launch");
     bool first = true;
@@ -812,7 +860,7 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
         TAHOE_HIP_TRY(hipMemsetAsync(q->chunk_flags, 0, q->n_chunk_flags * sizeof(uint32_t), stream));
         int cshift = 0;  // rows per quantise workgroup = rows per "missing seen" flag, as a shift
         {
-            const tahoe_status qs = quantize_launch(f, g, data, rows, trs, stream, &cshift);
+            const tahoe_status qs = quantize_launch(f, g, data, rows, trs, q->reg ? 1 : 0, stream, &cshift);
             if (qs != TAHOE_OK) return qs;
         }
         TAHOE_HIP_TRY(hipGetLastError());
@@ -829,7 +877,11 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
         else
         switch (nwalk) {
             case 15:
-                if (q->narrow && f->relayout)
+                if (q->reg && chains == 3)
+                    q_launch<kReg3Walkers, true, true, false, 3, true, kReg3Ring>(f, g, sums, sums_in, leaf_out, rows, stream, cshift);
+                else if (q->reg)
+                    q_launch<15, true, true, false, 2, true>(f, g, sums, sums_in, leaf_out, rows, stream, cshift);
+                else if (q->narrow && f->relayout)
                     q_launch<15, true, true, true>(f, g, sums, sums_in, leaf_out, rows, stream, cshift);
                 else if (q->narrow)
                     q_launch<15, true, true>(f, g, sums, sums_in, leaf_out, rows, stream, cshift);

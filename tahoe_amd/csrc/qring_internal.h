@@ -40,6 +40,7 @@ struct tahoe_qstate {
     bool have_mid = false;        // De - 2 > top_levels: heap of quantised nodes for the middle levels
     int top_stride = 0;           // u32 entries per tree in `top` (>= 4)
     bool narrow = false;          // node words in the NARROW layout (num_cols <= 256, 15 walkers, LDS tile)
+    bool reg = false;             // ... in its region form: fid << 7, tiles of two or three 64-row regions (qring.hip)
     int wide_rt = 0;              // rows per tile of the wide-row form (qwide_kernel), fixed at create; 0 = not used
     int wide_lw = 0;              // ... and the top levels its LDS slots hold
     std::vector<tahoe_qgroup> groups;
@@ -64,6 +65,12 @@ constexpr int kQRing = TAHOE_QRING_RING;    // ring entries (trees)
 constexpr int kQBatch = TAHOE_QRING_BATCH;  // trees the consumer takes per poll
 constexpr int kQSpinLimit = 1 << 22;
 constexpr int kQSlotBytes = 4096;            // LDS per walker: a 10-level top (2^10 u32)
+// Region form (NARROW, num_cols <= 256): a tile is K regions of 64 rows, each [fid][64] u16 at a multiple of 32 KiB in LDS.
+// K = 3: 13 walkers x 3 chains and a ring of 15 (96 + 52 + 11.3 KiB); K = 2: 15 walkers x 2 chains, ring of 24.
+constexpr int kRegRows = 64;
+constexpr int kRegBytes = 32768;
+constexpr int kReg3Walkers = 13;
+constexpr int kReg3Ring = 15;
 constexpr int kQMaxTable = 32767;
 #ifndef TAHOE_QUANT_MAX_SHIFT
 #define TAHOE_QUANT_MAX_SHIFT 16  // K3: 15 -> 0.907 ms, 16 -> 0.874 ms (half the table staging per row)
@@ -78,10 +85,15 @@ constexpr uint32_t kCodeMissing = 0xFFFFu;
 __host__ __device__ __forceinline__ int qrow_pos(int r) { return ((r & 31) << 1) | ((r >> 5) & 1) | ((r >> 6) << 6); }
 // index of (row r, feature f) in the quantised workspace: tiles of 2^trs rows, xq[tile][f][2^trs]; 128-row tiles
 // permute the rows inside a column (qrow_pos), the smaller tiles of the wide-row form keep them in order
-__device__ __forceinline__ size_t q_tile_index(size_t r, int f, int cols, int trs)
+// slot of row r (0..63) inside a 128-byte column of a 64-row REGION: lanes 0..31 of a wave land in 32 different banks,
+// lanes 32..63 in the upper halves of the same dwords
+__host__ __device__ __forceinline__ int qreg_pos(int r) { return ((r & 31) << 1) | (r >> 5); }
+// `perm` (with trs = 6): the region layout of the NARROW walk -- xq[region = r / 64][f][64] with qreg_pos slots; a walk tile
+// is K consecutive regions (K = 2 or 3, chosen per batch), so the quantise pass does not depend on K.
+__device__ __forceinline__ size_t q_tile_index(size_t r, int f, int cols, int trs, int perm = 0)
 {
     const int rr = (int)(r & (((size_t)1 << trs) - 1));
-    return (((r >> trs) * (size_t)cols + (size_t)f) << trs) + (size_t)(trs == 7 ? qrow_pos(rr) : rr);
+    return (((r >> trs) * (size_t)cols + (size_t)f) << trs) + (size_t)(trs == 7 ? qrow_pos(rr) : perm ? qreg_pos(rr) : rr);
 }
 
 constexpr int kQuantPairThreads = 1024;
@@ -146,11 +158,12 @@ typedef const uint16_t __attribute__((address_space(3))) *lds_u16_ptr;
 template <bool LDSX, bool NARROW, int CSHIFT = 8>
 __device__ __forceinline__ uint32_t q_xread(const unsigned char *gx, uint32_t node, uint32_t posb)
 {
-    static_assert(!NARROW || CSHIFT == 8, "the NARROW layout is defined for 256-byte feature columns");
+    static_assert(!NARROW || CSHIFT == 8 || CSHIFT == 7, "the NARROW layouts have 256- or 128-byte feature columns");
     if (LDSX && NARROW) {
-        // the tile starts at LDS address 0 (checked at kernel entry) and posb < 256: address = node[15:8] : posb[7:0]
+        // The tile starts at LDS address 0 (checked at kernel entry).  CSHIFT = 8: posb < 256, address = node[15:8] : posb[7:0].
+        // CSHIFT = 7 (64-row regions at multiples of 32 KiB): posb = region base + slot (< 128), address takes node[14:7].
         uint32_t addr;
-        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(addr) : "s"(0xFF00u), "v"(node), "v"(posb));
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(addr) : "s"(0xFFu << (CSHIFT == 7 ? 7 : 8)), "v"(node), "v"(posb));
         return *reinterpret_cast<lds_u16_ptr>(addr);
     }
     if (LDSX) {
@@ -170,8 +183,8 @@ void quantize_free_tables(tahoe_qgroup &g);
 hipError_t quantize_allow_lds(const tahoe_forest *f);  // kernels that need more than 64 KiB of dynamic LDS
 // Launches the quantise pass of group g for `rows` rows of `data` into f->q->xq (tiles of 2^trs rows) and the
 // per-chunk "missing seen" flags; *cshift_out = log2 of the rows per flag.
-tahoe_status quantize_launch(tahoe_forest *f, const tahoe_qgroup &g, const float *data, size_t rows, int trs, hipStream_t stream,
-                             int *cshift_out);
+tahoe_status quantize_launch(tahoe_forest *f, const tahoe_qgroup &g, const float *data, size_t rows, int trs, int perm,
+                             hipStream_t stream, int *cshift_out);
 
 }  // namespace tahoe
 

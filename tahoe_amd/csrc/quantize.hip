@@ -32,7 +32,7 @@ template <int F>
 __global__ void __launch_bounds__(kQuantThreads) quantize_kernel(const float *__restrict__ data, const float *__restrict__ tables,
                                                                  const int *__restrict__ offsets, uint16_t *__restrict__ xq,
                                                                  uint32_t *__restrict__ chunk_flags, size_t rows, int cols,
-                                                                 float missing, int tab_stride, int trs, int cshift)
+                                                                 float missing, int tab_stride, int trs, int cshift, int perm)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *tab = reinterpret_cast<float *>(smem);
@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(kQuantThreads) quantize_kernel(const float *__
                     const bool ms = fabsf(x[u] - missing) <= kMissingEps;
                     saw_missing |= ms;
                     const uint32_t code = ms ? kCodeMissing : (uint32_t)(cnt[u] - size[j]);
-                    xq[q_tile_index(r, f0 + j, cols, trs)] =
+                    xq[q_tile_index(r, f0 + j, cols, trs, perm)] =
                         (uint16_t)code;
                 }
             }
@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(kQuantThreads) quantize_kernel(const float *__
 __global__ void __launch_bounds__(kQuantPairThreads)
     quantize_pair_kernel(const float *__restrict__ data, const float *__restrict__ tables, const int *__restrict__ offsets,
                          uint16_t *__restrict__ xq, uint32_t *__restrict__ chunk_flags, size_t rows, int cols, float missing,
-                         int lds_floats, int trs, int cshift)
+                         int lds_floats, int trs, int cshift, int perm)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *tab = reinterpret_cast<float *>(smem);
@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(kQuantPairThreads)
             for (int u = 0; u < U; ++u) {
                 const size_t r = rb + (size_t)u * blockDim.x;
                 if (r < r1) {
-                    uint16_t *dst = xq + q_tile_index(r, f0, cols, trs);
+                    uint16_t *dst = xq + q_tile_index(r, f0, cols, trs, perm);
                     if (do0) {
                         const bool ms = fabsf(xv[u].x - missing) <= kMissingEps;
                         saw_missing |= ms;
@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(kQuantPairThreads)
     quantize_bucket_pair_kernel(const float *__restrict__ data, const float *__restrict__ bsorted, const int *__restrict__ boffsets,
                                 const uint16_t *__restrict__ bstarts, const float4 *__restrict__ bparams,
                                 uint16_t *__restrict__ xq, uint32_t *__restrict__ chunk_flags, size_t rows, int cols, float missing,
-                                int B, int trs, int cshift)
+                                int B, int trs, int cshift, int perm)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned nblk = gridDim.x;
@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(kQuantPairThreads)
         for (int u = 0; u < U; ++u) {
             const size_t r = rb + (size_t)u * blockDim.x;
             if (r < r1) {
-                uint16_t *dst = xq + q_tile_index(r, f0, cols, trs);
+                uint16_t *dst = xq + q_tile_index(r, f0, cols, trs, perm);
                 const bool ms0 = fabsf(xv[u].x - missing) <= kMissingEps, ms1 = fabsf(xv[u].y - missing) <= kMissingEps;
                 saw_missing |= ms0 | ms1;
                 dst[0] = (uint16_t)(ms0 ? kCodeMissing : (uint32_t)c0[u]);
@@ -322,7 +322,7 @@ template <int Q>
 __global__ void __launch_bounds__(kQuantPairThreads)
     quantize_multi_kernel(const float *__restrict__ data, const float *__restrict__ tables, const int *__restrict__ offsets,
                           uint16_t *__restrict__ xq, uint32_t *__restrict__ chunk_flags, size_t rows, int cols, float missing,
-                          int tab_stride, int trs, int cshift)
+                          int tab_stride, int trs, int cshift, int perm)
 {
     constexpr int F = 4 * Q;
     constexpr int RPI = kQuantPairThreads / Q;  // rows per block iteration
@@ -382,7 +382,7 @@ __global__ void __launch_bounds__(kQuantPairThreads)
                 if (r < r1) {
                     const bool ms = fabsf(x[u] - missing) <= kMissingEps;
                     saw_missing |= ms;
-                    xq[q_tile_index(r, fq + j, cols, trs)] = (uint16_t)(ms ? kCodeMissing : (uint32_t)(cnt[u] - size[j]));
+                    xq[q_tile_index(r, fq + j, cols, trs, perm)] = (uint16_t)(ms ? kCodeMissing : (uint32_t)(cnt[u] - size[j]));
                 }
             }
         }
@@ -597,8 +597,8 @@ hipError_t quantize_allow_lds(const tahoe_forest *f)
     return hipSuccess;
 }
 
-tahoe_status quantize_launch(tahoe_forest *f, const tahoe_qgroup &g, const float *data, size_t rows, int trs, hipStream_t stream,
-                             int *cshift_out)
+tahoe_status quantize_launch(tahoe_forest *f, const tahoe_qgroup &g, const float *data, size_t rows, int trs, int perm,
+                             hipStream_t stream, int *cshift_out)
 {
     tahoe_qstate *q = f->q;
     const bool pair_ok = g.pair_lds_floats > 0 && (reinterpret_cast<uintptr_t>(data) % 8) == 0;  // float2 loads
@@ -621,23 +621,23 @@ tahoe_status quantize_launch(tahoe_forest *f, const tahoe_qgroup &g, const float
     if (multi_ok && g.multi_q == 4)
         hipLaunchKernelGGL(quantize_multi_kernel<4>, dim3((unsigned)qgrid), dim3(kQuantPairThreads),
                            (size_t)16 * std::max(g.max_table, 1) * 4, stream, data, g.tables, g.offsets, q->xq, q->chunk_flags,
-                           rows, f->p.num_cols, f->p.missing, std::max(g.max_table, 1), trs, cshift);
+                           rows, f->p.num_cols, f->p.missing, std::max(g.max_table, 1), trs, cshift, perm);
     else if (multi_ok)
         hipLaunchKernelGGL(quantize_multi_kernel<2>, dim3((unsigned)qgrid), dim3(kQuantPairThreads),
                            (size_t)8 * std::max(g.max_table, 1) * 4, stream, data, g.tables, g.offsets, q->xq, q->chunk_flags,
-                           rows, f->p.num_cols, f->p.missing, std::max(g.max_table, 1), trs, cshift);
+                           rows, f->p.num_cols, f->p.missing, std::max(g.max_table, 1), trs, cshift, perm);
     else if (pair_ok && g.buckets > 0)
         hipLaunchKernelGGL(quantize_bucket_pair_kernel, dim3((unsigned)qgrid), dim3(kQuantPairThreads),
                            (size_t)g.bucket_lds_bytes, stream, data, g.bsorted, g.boffsets, g.bstarts, g.bparams, q->xq,
-                           q->chunk_flags, rows, f->p.num_cols, f->p.missing, g.buckets, trs, cshift);
+                           q->chunk_flags, rows, f->p.num_cols, f->p.missing, g.buckets, trs, cshift, perm);
     else if (pair_ok)
         hipLaunchKernelGGL(quantize_pair_kernel, dim3((unsigned)qgrid), dim3(kQuantPairThreads),
                            (size_t)g.pair_lds_floats * 4, stream, data, g.tables, g.offsets, q->xq, q->chunk_flags, rows,
-                           f->p.num_cols, f->p.missing, g.pair_lds_floats, trs, cshift);
+                           f->p.num_cols, f->p.missing, g.pair_lds_floats, trs, cshift, perm);
     else
         hipLaunchKernelGGL(quantize_kernel<1>, dim3((unsigned)qgrid), dim3(kQuantThreads), (size_t)std::max(g.max_table, 1) * 4,
                            stream, data, g.tables, g.offsets, q->xq, q->chunk_flags, rows, f->p.num_cols, f->p.missing,
-                           std::max(g.max_table, 1), trs, cshift);
+                           std::max(g.max_table, 1), trs, cshift, perm);
     TAHOE_HIP_TRY(hipGetLastError());
     *cshift_out = cshift;
     return TAHOE_OK;

@@ -300,6 +300,39 @@ def test_predict_accumulate_continues_the_sum_on_every_strategy(env):
         assert np.array_equal(bits(got.cpu().numpy()), bits(want)), s
 
 
+def test_region_form_two_and_three_chains(env, monkeypatch):
+    """QRING's region layout (num_cols <= 256): tiles of three 64-row regions (13 walkers x 3 chains) or two (15 x 2), picked
+    per batch; both forced here, plus the 128-slot column layout it replaces, on ragged row counts, with missing values
+    confined to a few rows so that a 192-row tile straddles a quantise chunk that saw none and one that did."""
+    ta, oracle, torch = env
+    T, D, C, R = 45, 9, 200, 3000
+    nodes = ta.synth_forest(T, D, C, seed=81, leaf_prob=0.03)
+    data = ta.synth_data(R, C, seed=82)
+    data[500:530, ::7] = MISSING      # quantise chunks are >= 512 rows: rows 384..575 form a 192-row tile across chunks 0 and 1
+    data[2000, 3] = MISSING
+    want, want_leaf = oracle.predict(nodes, T, D, data, MISSING, want_leaf=True, threads=4)
+    x = torch.from_numpy(data).cuda()
+    for env_set in ({"TAHOE_QRING_CHAINS": "3"}, {"TAHOE_QRING_CHAINS": "2"}, {"TAHOE_QRING_REGIONS": "0"}, {}):
+        for k, v in env_set.items():
+            monkeypatch.setenv(k, v)
+        forest = ta.Forest(nodes, T, D, C, missing=MISSING)
+        forest.set_strategy(ta.STRATEGY_QRING)
+        assert forest.info().qring_tile_rows == (128 if "TAHOE_QRING_REGIONS" in env_set else 192)
+        for rows in (1, 63, 64, 65, 191, 192, 193, 385, 577, 1000, R):
+            leaf, sums = forest.predict_leaf_idx(x[:rows].contiguous())
+            raw = forest.predict_raw(x[:rows].contiguous())
+            forest.check()
+            assert np.array_equal(bits(leaf.cpu().numpy()), want_leaf[:rows]), (env_set, rows)
+            assert np.array_equal(bits(sums.cpu().numpy()), bits(want[:rows])), (env_set, rows)
+            assert np.array_equal(bits(raw.cpu().numpy()), bits(want[:rows])), (env_set, rows)
+        cont = forest.predict_accumulate(x, torch.full((R,), 0.25, dtype=torch.float32, device="cuda"))
+        assert np.array_equal(bits(cont.cpu().numpy()),
+                              bits(oracle.predict_continue(nodes, T, D, data, MISSING, np.full(R, 0.25, dtype=np.float32))))
+        forest.close()
+        for k in env_set:
+            monkeypatch.delenv(k)
+
+
 def test_probability_relayout_keeps_every_result(env):
     """SURVEY 8f N3 (Struct.h:1775-1825): with TAHOE_CREATE_PROB_RELAYOUT the subtrees are ordered by dense_node_t.weight and
     marked nodes invert their condition; leaf indices (original heap numbering) and float32 sums must not change."""
