@@ -453,8 +453,8 @@ def k4_legs(args, ta, sharding, torch, coll, dist, world, rank, fence, max_over_
     if rank == 0:
         e, _, _ = errors(pa[:sample].cpu().numpy(), xa[:sample].cpu().numpy(), ncpu)
         leg.update(e)
-        if not e["bit_identical_to_cpu_f32"]:
-            raise RuntimeError("K4 row shard: sums differ from the CPU oracle")
+        if not e["bit_identical_to_cpu_f32"]:  # reported, not raised: the other ranks are on their way into the next collective
+            leg["error"] = "K4 row shard: sums differ from the CPU oracle"
     legs["row_sharded"] = leg
     fa.close()
     del fa, pa
@@ -482,15 +482,18 @@ def k4_legs(args, ta, sharding, torch, coll, dist, world, rank, fence, max_over_
                "collective": ("one all-reduce of 8 B/row (float64 partials)" if mode == "allreduce64" else
                               f"point-to-point hand-over of 4 B/row in chunks of {args.chunk_rows} rows") if world > 1 else
                              "not in the time (1 GPU: one of 8 shards); 8 MB all-reduce over xGMI expected << 1 ms"}
-        holder = (world - 1) if (world > 1 and mode == "chain") else 0
-        if world > 1 and rank == holder:
-            e, exact, a = errors(p4[:sample].cpu().numpy(), x4[:sample].cpu().numpy(), ncpu)
-            if mode == "chain" and not e["bit_identical_to_cpu_f32"]:
-                raise RuntimeError("K4 chained tree shards: sums differ from the CPU oracle")
-            if mode == "allreduce64":
-                bound = sharding.sum_error_bound(a, exact, trees_per_shard=(T4 + world - 1) // world)
-                e["within_stated_bound"] = bool(np.all(np.abs(p4[:sample].cpu().numpy().astype(np.float64) - exact) <= bound))
-            leg.update(e)
+        if world > 1:
+            got = p4[:sample].clone()
+            if mode == "chain":  # the last rank of the chain holds the sums: hand the checked rows to rank 0, which reports
+                coll.broadcast(got, src=world - 1)
+            if rank == 0:
+                e, exact, a = errors(got.cpu().numpy(), x4[:sample].cpu().numpy(), ncpu)
+                if mode == "chain" and not e["bit_identical_to_cpu_f32"]:
+                    leg["error"] = "K4 chained tree shards: sums differ from the CPU oracle"
+                if mode == "allreduce64":
+                    bound = sharding.sum_error_bound(a, exact, trees_per_shard=(T4 + world - 1) // world)
+                    e["within_stated_bound"] = bool(np.all(np.abs(got.cpu().numpy().astype(np.float64) - exact) <= bound))
+                leg.update(e)
         legs["tree_sharded_" + mode] = leg
     if world == 1:
         # accuracy of the 8-shard all-reduce, emulated on this GPU on the row sample: eight shard forests, float64 combine
@@ -514,7 +517,7 @@ def k4_legs(args, ta, sharding, torch, coll, dist, world, rank, fence, max_over_
         ec["emulated"] = f"{G} shard forests on this GPU, running float32 sums handed from shard to shard"
         legs["tree_sharded_chain_accuracy"] = ec
         if not ec["bit_identical_to_cpu_f32"]:
-            raise RuntimeError("K4 chained tree shards (emulated): sums differ from the CPU oracle")
+            ec["error"] = "K4 chained tree shards (emulated): sums differ from the CPU oracle"
         t_rows, t_trees = legs["row_sharded"]["ms_per_step"], legs["tree_sharded_allreduce64"]["ms_per_step"]
         legs["selector"] = {
             "choose_sharding": sharding.choose_sharding(T4, D),
