@@ -212,7 +212,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
             const int e = t % RING;
     #pragma unroll
             for (int k = 0; k < K; ++k) ring_vals[e * TR + k * 64 + lane] = v[k];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // values before the flag (in-order LDS)
+            asm volatile("" ::: "memory");  // values before the flag: a wave's LDS operations are performed in issue order
             if (lane == 0) lds_flag_store(&ring_ready[e], (uint32_t)(t + 1));
         };
         int t_p = -1;  // tree whose bottom blocks are in flight
