@@ -77,6 +77,7 @@ struct tahoe_forest {
     size_t relayout_swaps = 0;
     int knob_tile_rows = 0;
     int knob_qring_walkers = 0;
+    int knob_qring_slices = 0;  // TAHOE_QRING_SLICES >= 1: force the tree slices per tile of QRING's SPLIT form
     int knob_qring_chains = 0;  // TAHOE_QRING_CHAINS = 2 / 3: force the tile form of QRING's region layout
     // Profiling: one hipEvent pair per traversal launch, read back after the stream has drained.
     bool profiling = false;

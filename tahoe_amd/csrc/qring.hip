@@ -47,14 +47,21 @@ namespace tahoe {
 // one v_bfi forms the read address), chain k of a lane walks row 64 k + lane.  K = 3: a top staged once serves 192 rows
 // (profiles/r02/tiles_experiment.json: almost half of a tile's time does not depend on its rows) with 13 walkers and a
 // ring of 15; K = 2 (15 walkers, ring of 24) for batches that fill the chip better with 128-row tiles.
-template <int NWALK, bool WRITE_LEAF, bool LDSX, bool NARROW = false, bool EXCH = false, int K = 2, bool REG = false, int RING = kQRing>
+// SPLIT (small batches; the counterpart of the reference's split-forest strategy idx 4, Struct.h:1414-1606 + :2103-2164): when a
+// batch has fewer tiles than the chip has CUs, every tile is given to `slices` workgroups that each walk a slice of the trees
+// and write the leaf values to leafbuf[tree][row]; ordered_sum_kernel then adds them per row in tree order -- the same
+// sequential float32 sum, where the reference's cub::DeviceSegmentedReduce adds per-block partial sums in another order.
+template <int NWALK, bool WRITE_LEAF, bool LDSX, bool NARROW = false, bool EXCH = false, int K = 2, bool REG = false, int RING = kQRing,
+          bool SPLIT = false>
 __global__ void __launch_bounds__((NWALK + 1) * 64)
     qring_kernel(const uint16_t *__restrict__ xq, const uint32_t *__restrict__ top, const uint4 *__restrict__ blocks,
                  const uint32_t *__restrict__ qinner, const uint32_t *__restrict__ leaf_orig, float *__restrict__ sums,
                  uint32_t *__restrict__ leaf_out, size_t rows, int cols, int num_trees, int depth, int top_levels,
                  int top_stride, const uint32_t *__restrict__ chunk_flags, int *__restrict__ error_flag,
-                 const float *sums_in, int tree_base, int total_trees, int cshift)
+                 const float *sums_in, int tree_base, int total_trees, int cshift, float *__restrict__ leafbuf, size_t leaf_stride,
+                 int slices)
 {
+    static_assert(!SPLIT || REG, "tree slices are a form of the region kernel");
     static_assert(REG || K == kQRows / 64, "the 128-slot column layout holds exactly two chains");
     static_assert(!REG || (LDSX && NARROW && !EXCH), "regions are a form of the NARROW LDS tile");
     static_assert(RING > NWALK && RING >= 2 * kQBatch, "ring too small");
@@ -68,13 +75,17 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
     constexpr int slot_bytes = kQSlotBytes;  // fixed 4 KiB slot (2^10 u32): no size-dependent branches in the loop
 
     uint16_t *tile = reinterpret_cast<uint16_t *>(smem);  // LDSX only
+    const unsigned tile_id = SPLIT ? blockIdx.x / (unsigned)slices : blockIdx.x;
+    const int slice = SPLIT ? (int)(blockIdx.x % (unsigned)slices) : 0;
+    const int t_begin = SPLIT ? (int)((long long)num_trees * slice / slices) : 0;        // this workgroup's trees
+    const int t_end = SPLIT ? (int)((long long)num_trees * (slice + 1) / slices) : num_trees;
     unsigned char *slots = smem + (REG ? (size_t)K * kRegBytes : LDSX ? (size_t)cols * TR * sizeof(uint16_t) : 0);
-    const unsigned char *gx = reinterpret_cast<const unsigned char *>(xq + (size_t)blockIdx.x * ((size_t)cols * TR));
+    const unsigned char *gx = reinterpret_cast<const unsigned char *>(xq + (size_t)tile_id * ((size_t)cols * TR));
     float *ring_vals = reinterpret_cast<float *>(slots + (size_t)NWALK * slot_bytes);
     uint32_t *ring_ready = reinterpret_cast<uint32_t *>(ring_vals + RING * TR);
     uint32_t *consumed = ring_ready + RING;
 
-    const size_t row0 = (size_t)blockIdx.x * TR;
+    const size_t row0 = (size_t)tile_id * TR;
     if (LDSX && NARROW && (uint32_t)reinterpret_cast<uintptr_t>(tile) != 0u) {
         // q_xread's v_bfi needs the tile at LDS address 0 (true while the kernel has no static LDS)
         if (tid == 0) atomicOr(error_flag, 2);
@@ -85,12 +96,12 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
     if (REG) {  // K consecutive regions of the workspace, each to its 32-KiB-aligned place
         const int n16 = cols * kRegRows * 2 / 16;  // 16-byte pieces of a region
         for (int k = 0; k < K; ++k) {
-            const uint4 *src = reinterpret_cast<const uint4 *>(xq + ((size_t)blockIdx.x * K + k) * ((size_t)cols * kRegRows));
+            const uint4 *src = reinterpret_cast<const uint4 *>(xq + ((size_t)tile_id * K + k) * ((size_t)cols * kRegRows));
             uint4 *dst = reinterpret_cast<uint4 *>(smem + (size_t)k * kRegBytes);
             for (int e = tid; e < n16; e += NT) dst[e] = src[e];
         }
     } else if (LDSX) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(xq + (size_t)blockIdx.x * ((size_t)cols * TR));
+        const uint4 *src = reinterpret_cast<const uint4 *>(xq + (size_t)tile_id * ((size_t)cols * TR));
         uint4 *dst = reinterpret_cast<uint4 *>(tile);
         const int n16 = cols * TR * 2 / 16;
         for (int e = tid; e < n16; e += NT) dst[e] = src[e];
@@ -101,6 +112,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
     if (wave == NWALK) {
         // ================= consumer: ordered accumulation =================
         __syncthreads();
+        if (SPLIT) return;  // the leaf values go to leafbuf; ordered_sum_kernel adds them
         float sum[K];  // continues the running sums of the previous tree group (sums_in may alias sums)
 #pragma unroll
         for (int k = 0; k < K; ++k) {
@@ -163,8 +175,8 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
         s[2 * 64 + lane] = pf2;
         s[3 * 64 + lane] = pf3;
     };
-    if (wave < num_trees) {
-        prefetch_top(wave);
+    if (t_begin + wave < t_end) {
+        prefetch_top(t_begin + wave);
         commit_top();
     }
     __syncthreads();  // the tile, the ring state and (own wave) the first top are in LDS
@@ -199,6 +211,14 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                             leaf_orig[(size_t)t * ((size_t)n_blocks * 4) + (size_t)bs[k] * 4 + 2 * (c0 ? 1 : 0) + (c1 ? 1 : 0)];
                 }
             }
+            if (SPLIT) {  // straight to leafbuf[tree][row]: 64 consecutive floats per chain
+    #pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const size_t row = row0 + k * 64 + lane;
+                    if (row < rows) leafbuf[(size_t)t * leaf_stride + row] = v[k];
+                }
+                return;
+            }
             if (t >= RING) {  // ring entry still in use by tree t - RING?
                 int spins = 0;
                 while (lds_flag_load(consumed) < (uint32_t)(t - RING + 1)) {
@@ -218,8 +238,8 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
         int t_p = -1;  // tree whose bottom blocks are in flight
         uint4 na_p[K] = {}, nb_p[K] = {};
         uint32_t bsel_p[K] = {};
-        for (int t = wave; t < num_trees && !dead; t += NWALK) {
-            const bool more = t + NWALK < num_trees;
+        for (int t = t_begin + wave; t < t_end && !dead; t += NWALK) {
+            const bool more = t + NWALK < t_end;
             if (more) prefetch_top(t + NWALK);
             uint32_t i[K];
     #pragma unroll
@@ -485,6 +505,25 @@ __global__ void __launch_bounds__(16 * 64)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Second step of the SPLIT form: per row, the leaf values of the group's trees in tree order, continuing sums_in.
+__global__ void __launch_bounds__(256) ordered_sum_kernel(const float *__restrict__ leafbuf, size_t leaf_stride, int num_trees,
+                                                          const float *sums_in, float *__restrict__ sums, size_t rows)
+{
+    const size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    float sum = sums_in ? sums_in[row] : 0.0f;
+    int t = 0;
+    for (; t + 8 <= num_trees; t += 8) {  // eight loads in flight, eight adds in order
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = leafbuf[(size_t)(t + j) * leaf_stride + row];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += v[j];
+    }
+    for (; t < num_trees; ++t) sum += leafbuf[(size_t)t * leaf_stride + row];
+    sums[row] = sum;
+}
+
 // LDS of the region form: K regions of 32 KiB, walker slots, ring
 static long long qreg_lds_for(int k, int nwalk, int ring)
 {
@@ -561,7 +600,9 @@ static hipError_t q_allow(long long lds)
                           (const void *)&qring_kernel<15, false, true, true, true>, (const void *)&qring_kernel<15, true, true, true, true>,
                           (const void *)&qring_kernel<15, false, true, true, false, 2, true>, (const void *)&qring_kernel<15, true, true, true, false, 2, true>,
                           (const void *)&qring_kernel<kReg3Walkers, false, true, true, false, 3, true, kReg3Ring>,
-                          (const void *)&qring_kernel<kReg3Walkers, true, true, true, false, 3, true, kReg3Ring>})
+                          (const void *)&qring_kernel<kReg3Walkers, true, true, true, false, 3, true, kReg3Ring>,
+                          (const void *)&qring_kernel<15, false, true, true, false, 2, true, kQRing, true>,
+                          (const void *)&qring_kernel<15, true, true, true, false, 2, true, kQRing, true>})
         if ((e = allow_max_lds(k, (int)lds)) != hipSuccess) return e;
     return hipSuccess;
 }
@@ -685,6 +726,7 @@ tahoe_status qring_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner,
         const char *e = getenv("TAHOE_QRING_REGIONS");  // experiments: 0 keeps the 128-slot column layout
         q->reg = q->narrow && !f->relayout && qreg_lds_for(3, kReg3Walkers, kReg3Ring) <= f->lds_limit && !(e && atoi(e) == 0);
         if (const char *k = getenv("TAHOE_QRING_CHAINS")) f->knob_qring_chains = atoi(k);  // 2 / 3: force the tile form
+        if (const char *k = getenv("TAHOE_QRING_SLICES")) f->knob_qring_slices = atoi(k);  // >= 1: force the tree slices per tile
     }
     if (f->relayout && !q->narrow) {  // only the NARROW node word has room for the exchange bit: the strategy steps aside
         qring_destroy(f);
@@ -757,6 +799,7 @@ void qring_destroy(tahoe_forest *f)
     if (!q) return;
     for (tahoe_qgroup &g : q->groups) free_group(g);
     if (q->xq) (void)hipFree(q->xq);
+    if (q->leafbuf) (void)hipFree(q->leafbuf);
     if (q->chunk_flags) (void)hipFree(q->chunk_flags);
     delete q;
     f->q = nullptr;
@@ -766,6 +809,9 @@ int qring_groups(const tahoe_forest *f) { return f->q ? (int)f->q->groups.size()
 bool qring_regions(const tahoe_forest *f) { return f->q && f->q->reg; }
 
 // The quantised copy of the batch lives in a grow-only workspace owned by the handle.
+static int q_slices(const tahoe_forest *f, size_t rows, int *most_out);
+static tahoe_status qring_reserve_leafbuf(tahoe_forest *f, size_t rows, int trees);
+
 tahoe_status qring_reserve(tahoe_forest *f, size_t rows)
 {
     tahoe_qstate *q = f->q;
@@ -773,40 +819,89 @@ tahoe_status qring_reserve(tahoe_forest *f, size_t rows)
     size_t tiles = (rows + kQRows - 1) / kQRows;
     // region form: a walk tile reads two or three whole 64-row regions -> room for the last tile to read past the batch
     if (q->reg) tiles = ((rows + kRegRows - 1) / kRegRows + 2 + 1) / 2;
-    if (tiles * kQRows <= q->xq_rows) return TAHOE_OK;
-    if (q->xq) {
-        TAHOE_HIP_TRY(hipDeviceSynchronize());  // a previous launch may still read the old buffer
-        TAHOE_HIP_TRY(hipFree(q->xq));
-        f->device_bytes -= q->xq_rows * (size_t)f->p.num_cols * 2;
-        q->xq = nullptr;
-        q->xq_rows = 0;
+    if (tiles * kQRows > q->xq_rows) {
+        if (q->xq) {
+            TAHOE_HIP_TRY(hipDeviceSynchronize());  // a previous launch may still read the old buffer
+            TAHOE_HIP_TRY(hipFree(q->xq));
+            f->device_bytes -= q->xq_rows * (size_t)f->p.num_cols * 2;
+            q->xq = nullptr;
+            q->xq_rows = 0;
+        }
+        const size_t bytes = tiles * kQRows * (size_t)f->p.num_cols * sizeof(uint16_t);
+        TAHOE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&q->xq), bytes));
+        q->xq_rows = tiles * kQRows;
+        f->device_bytes += bytes;
+        if (q->chunk_flags) TAHOE_HIP_TRY(hipFree(q->chunk_flags));
+        q->chunk_flags = nullptr;
+        q->n_chunk_flags = (q->xq_rows + kQuantMinRowsPerBlock - 1) / kQuantMinRowsPerBlock + 1;
+        TAHOE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&q->chunk_flags), q->n_chunk_flags * sizeof(uint32_t)));
     }
-    const size_t bytes = tiles * kQRows * (size_t)f->p.num_cols * sizeof(uint16_t);
-    TAHOE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&q->xq), bytes));
-    q->xq_rows = tiles * kQRows;
-    f->device_bytes += bytes;
-    if (q->chunk_flags) TAHOE_HIP_TRY(hipFree(q->chunk_flags));
-    q->n_chunk_flags = (q->xq_rows + kQuantMinRowsPerBlock - 1) / kQuantMinRowsPerBlock + 1;
-    TAHOE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&q->chunk_flags), q->n_chunk_flags * sizeof(uint32_t)));
+    int most = 1;  // a batch small enough to be walked in tree slices also needs the leaf-value buffer
+    if (q_slices(f, rows, &most) > 1) return qring_reserve_leafbuf(f, rows, most);
     return TAHOE_OK;
 }
 
-template <int NWALK, bool LDSX = true, bool NARROW = false, bool EXCH = false, int K = 2, bool REG = false, int RING = kQRing>
-static void q_launch(tahoe_forest *f, const tahoe_qgroup &g, float *sums, const float *sums_in, uint32_t *leaf_out,
-                     size_t rows, hipStream_t stream, int cshift)
+// Small batches of the region form: with fewer 128-row tiles than CUs every tile is walked by `slices` workgroups, each a
+// slice of the trees (SPLIT) -- while a slice still gives every walker a few trees.  *most = trees of the largest group.
+static int q_slices(const tahoe_forest *f, size_t rows, int *most_out)
+{
+    const tahoe_qstate *q = f->q;
+    int most = 1;
+    for (const tahoe_qgroup &g : q->groups) most = std::max(most, g.num_trees);
+    *most_out = most;
+    if (!q->reg || rows == 0) return 1;
+    const size_t tiles = (rows + 127) / 128;
+    const int fit = (int)std::min<size_t>((size_t)std::max(f->num_cus, 1) / tiles, 8);
+    int slices = std::max(1, std::min(fit, most / (4 * 15)));
+    if (f->knob_qring_slices >= 1) slices = std::min(f->knob_qring_slices, most);
+    return slices;
+}
+
+// Leaf-value buffer of the SPLIT form, [trees of the largest group][rows rounded up to 64] floats, grow-only like the
+// quantised workspace (tahoe_forest_reserve sizes it too when the batch is small enough to be split).
+static tahoe_status qring_reserve_leafbuf(tahoe_forest *f, size_t rows, int trees)
 {
     tahoe_qstate *q = f->q;
-    const unsigned grid = (unsigned)((rows + 64 * K - 1) / (64 * K));
+    const size_t stride = (rows + 63) / 64 * 64;
+    if (q->leafbuf && stride <= q->leaf_stride && (size_t)trees <= q->leaf_trees) return TAHOE_OK;
+    if (q->leafbuf) {
+        TAHOE_HIP_TRY(hipDeviceSynchronize());
+        TAHOE_HIP_TRY(hipFree(q->leafbuf));
+        f->device_bytes -= q->leaf_stride * q->leaf_trees * sizeof(float);
+        q->leafbuf = nullptr;
+    }
+    const size_t ns = std::max(stride, q->leaf_stride), nt = std::max<size_t>((size_t)trees, q->leaf_trees);
+    TAHOE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&q->leafbuf), ns * nt * sizeof(float)));
+    q->leaf_stride = ns;
+    q->leaf_trees = nt;
+    f->device_bytes += ns * nt * sizeof(float);
+    return TAHOE_OK;
+}
+
+template <int NWALK, bool LDSX = true, bool NARROW = false, bool EXCH = false, int K = 2, bool REG = false, int RING = kQRing,
+          bool SPLIT = false>
+static void q_launch(tahoe_forest *f, const tahoe_qgroup &g, float *sums, const float *sums_in, uint32_t *leaf_out,
+                     size_t rows, hipStream_t stream, int cshift, int slices = 1)
+{
+    tahoe_qstate *q = f->q;
+    const unsigned grid = (unsigned)((rows + 64 * K - 1) / (64 * K)) * (unsigned)(SPLIT ? slices : 1);
+    float *leafbuf = SPLIT ? q->leafbuf : nullptr;
+    const size_t leaf_stride = SPLIT ? q->leaf_stride : 0;
     const int lds = REG ? (int)qreg_lds_for(K, NWALK, RING) : (int)qring_lds_for(f, NWALK, LDSX);
     const uint32_t *leaf_orig = f->leaf_orig + (size_t)g.tree_lo * f->n_leaf;
     if (leaf_out)
-        hipLaunchKernelGGL((qring_kernel<NWALK, true, LDSX, NARROW, EXCH, K, REG, RING>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, g.top,
+        hipLaunchKernelGGL((qring_kernel<NWALK, true, LDSX, NARROW, EXCH, K, REG, RING, SPLIT>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, g.top,
                            g.blocks, g.qinner, leaf_orig, sums, leaf_out, rows, f->p.num_cols, g.num_trees, f->depth,
-                           q->top_levels, q->top_stride, q->chunk_flags, f->error_flag, sums_in, g.tree_lo, f->p.num_trees, cshift);
+                           q->top_levels, q->top_stride, q->chunk_flags, f->error_flag, sums_in, g.tree_lo, f->p.num_trees, cshift, leafbuf, leaf_stride,
+                           slices);
     else
-        hipLaunchKernelGGL((qring_kernel<NWALK, false, LDSX, NARROW, EXCH, K, REG, RING>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, g.top,
+        hipLaunchKernelGGL((qring_kernel<NWALK, false, LDSX, NARROW, EXCH, K, REG, RING, SPLIT>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, g.top,
                            g.blocks, g.qinner, leaf_orig, sums, leaf_out, rows, f->p.num_cols, g.num_trees, f->depth,
-                           q->top_levels, q->top_stride, q->chunk_flags, f->error_flag, sums_in, g.tree_lo, f->p.num_trees, cshift);
+                           q->top_levels, q->top_stride, q->chunk_flags, f->error_flag, sums_in, g.tree_lo, f->p.num_trees, cshift, leafbuf, leaf_stride,
+                           slices);
+    if (SPLIT && sums)
+        hipLaunchKernelGGL(ordered_sum_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, leafbuf, leaf_stride, g.num_trees,
+                           sums_in, sums, rows);
 }
 
 template <int RT>
@@ -853,8 +948,13 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
         chains = 100 * w2 <= 144 * w3 ? 2 : 3;
         if (f->knob_qring_chains == 2 || f->knob_qring_chains == 3) chains = f->knob_qring_chains;
     }
-    if ((rows + (wide ? wide : kQRows) - 1) / (wide ? wide : kQRows) > 0x7fffffffu)
-        return fail(TAHOE_ERR_INVALID_ARG, "too many rows for one launch");
+    int most = 1;
+    const int slices = q_slices(f, rows, &most);  // small batches of the region form: tree slices per tile (SPLIT)
+    if (slices > 1) {
+        const tahoe_status ls = qring_reserve_leafbuf(f, rows, most);  // no-op after tahoe_forest_reserve / a first predict
+        if (ls != TAHOE_OK) return ls;
+        chains = 2;
+    }
     bool first = true;
     for (const tahoe_qgroup &g : q->groups) {  // stream order: quantise for the group, walk the group, next group
         TAHOE_HIP_TRY(hipMemsetAsync(q->chunk_flags, 0, q->n_chunk_flags * sizeof(uint32_t), stream));
@@ -877,7 +977,9 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
         else
         switch (nwalk) {
             case 15:
-                if (q->reg && chains == 3)
+                if (q->reg && slices > 1)
+                    q_launch<15, true, true, false, 2, true, kQRing, true>(f, g, sums, sums_in, leaf_out, rows, stream, cshift, slices);
+                else if (q->reg && chains == 3)
                     q_launch<kReg3Walkers, true, true, false, 3, true, kReg3Ring>(f, g, sums, sums_in, leaf_out, rows, stream, cshift);
                 else if (q->reg)
                     q_launch<15, true, true, false, 2, true>(f, g, sums, sums_in, leaf_out, rows, stream, cshift);

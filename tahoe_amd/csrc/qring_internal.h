@@ -46,6 +46,8 @@ struct tahoe_qstate {
     std::vector<tahoe_qgroup> groups;
     uint16_t *xq = nullptr;       // workspace: quantised tiles (re-used by every group)
     size_t xq_rows = 0;           // rows the workspace holds
+    float *leafbuf = nullptr;     // workspace of the SPLIT form: [tree][row] leaf values of one tree group
+    size_t leaf_stride = 0, leaf_trees = 0;
     uint32_t *chunk_flags = nullptr;  // workspace: per 2^cshift rows (the rows of one quantise workgroup), "a missing value was seen"
     size_t n_chunk_flags = 0;
 };

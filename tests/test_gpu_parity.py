@@ -333,6 +333,42 @@ def test_region_form_two_and_three_chains(env, monkeypatch):
             monkeypatch.delenv(k)
 
 
+def test_small_batches_walked_in_tree_slices(env, monkeypatch):
+    """QRING's SPLIT form (the counterpart of the reference's split-forest strategy idx 4): a batch with fewer tiles than CUs
+    gives every tile to several workgroups, each a slice of the trees, and a second kernel adds the leaf values per row in
+    tree order -- same bits as the sequential sum.  Forced slice counts and the automatic choice, tree groups, continued sums."""
+    ta, oracle, torch = env
+    rng = np.random.default_rng(9)
+    for (T, D, C, R, lp) in [(500, 8, 18, 10_000, 0.05), (130, 6, 64, 777, 0.1), (700, 8, 4, 500, 0.0), (61, 3, 7, 129, 0.2)]:
+        nodes = ta.synth_forest(T, D, C, seed=91, leaf_prob=lp)
+        data = ta.synth_data(R, C, seed=92, missing_prob=0.02, missing=MISSING)
+        want, want_leaf = oracle.predict(nodes, T, D, data, MISSING, want_leaf=True, threads=8)
+        start = rng.standard_normal(R).astype(np.float32)
+        cont = oracle.predict_continue(nodes, T, D, data, MISSING, start.copy(), threads=8)
+        x = torch.from_numpy(data).cuda()
+        for slices in (None, "1", "2", "3", "8", "64"):
+            if slices is None:
+                monkeypatch.delenv("TAHOE_QRING_SLICES", raising=False)
+            else:
+                monkeypatch.setenv("TAHOE_QRING_SLICES", slices)
+            forest = ta.Forest(nodes, T, D, C, missing=MISSING)
+            forest.set_strategy(ta.STRATEGY_QRING)
+            assert forest.info().qring_tile_rows == 192
+            for rows in sorted({1, 65, 128, 129, R}):
+                if rows > R:
+                    continue
+                leaf, sums = forest.predict_leaf_idx(x[:rows].contiguous())
+                raw = forest.predict_raw(x[:rows].contiguous())
+                forest.check()
+                assert np.array_equal(bits(leaf.cpu().numpy()), want_leaf[:rows]), (T, C, slices, rows)
+                assert np.array_equal(bits(sums.cpu().numpy()), bits(want[:rows])), (T, C, slices, rows)
+                assert np.array_equal(bits(raw.cpu().numpy()), bits(want[:rows])), (T, C, slices, rows)
+            got = forest.predict_accumulate(x, torch.from_numpy(start.copy()).cuda())
+            assert np.array_equal(bits(got.cpu().numpy()), bits(cont)), (T, C, slices)
+            forest.close()
+    monkeypatch.delenv("TAHOE_QRING_SLICES", raising=False)
+
+
 def test_probability_relayout_keeps_every_result(env):
     """SURVEY 8f N3 (Struct.h:1775-1825): with TAHOE_CREATE_PROB_RELAYOUT the subtrees are ordered by dense_node_t.weight and
     marked nodes invert their condition; leaf indices (original heap numbering) and float32 sums must not change."""
