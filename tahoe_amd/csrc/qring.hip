@@ -45,14 +45,14 @@ namespace tahoe {
 // REG (the form K3 runs; NARROW node words with fid << 7, num_cols <= 256): the tile is K regions of 64 rows, region k =
 // [fid][64] u16 at LDS address k * 32 KiB (so that the column offset fid * 128 and the region base never share a bit and
 // one v_bfi forms the read address), chain k of a lane walks row 64 k + lane.  K = 3: a top staged once serves 192 rows
-// (profiles/r02/tiles_experiment.json: almost half of a tile's time does not depend on its rows) with 13 walkers and a
-// ring of 15; K = 2 (15 walkers, ring of 24) for batches that fill the chip better with 128-row tiles.
+// (profiles/r02/tiles_experiment.json: almost half of a tile's time does not depend on its rows) with 14 walkers and a
+// ring of 10; K = 2 (15 walkers, ring of 24) for batches that fill the chip better with 128-row tiles.
 // SPLIT (small batches; the counterpart of the reference's split-forest strategy idx 4, Struct.h:1414-1606 + :2103-2164): when a
 // batch has fewer tiles than the chip has CUs, every tile is given to `slices` workgroups that each walk a slice of the trees
 // and write the leaf values to leafbuf[tree][row]; ordered_sum_kernel then adds them per row in tree order -- the same
 // sequential float32 sum, where the reference's cub::DeviceSegmentedReduce adds per-block partial sums in another order.
 template <int NWALK, bool WRITE_LEAF, bool LDSX, bool NARROW = false, bool EXCH = false, int K = 2, bool REG = false, int RING = kQRing,
-          bool SPLIT = false>
+          bool SPLIT = false, int BATCH = (RING >= 2 * kQBatch ? kQBatch : RING / 2)>
 __global__ void __launch_bounds__((NWALK + 1) * 64)
     qring_kernel(const uint16_t *__restrict__ xq, const uint32_t *__restrict__ top, const uint4 *__restrict__ blocks,
                  const uint32_t *__restrict__ qinner, const uint32_t *__restrict__ leaf_orig, float *__restrict__ sums,
@@ -64,7 +64,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
     static_assert(!SPLIT || REG, "tree slices are a form of the region kernel");
     static_assert(REG || K == kQRows / 64, "the 128-slot column layout holds exactly two chains");
     static_assert(!REG || (LDSX && NARROW && !EXCH), "regions are a form of the NARROW LDS tile");
-    static_assert(RING > NWALK && RING >= 2 * kQBatch, "ring too small");
+    static_assert(BATCH >= 1 && RING >= 2 * BATCH, "ring too small");
     constexpr int TR = 64 * K;             // rows per tile
     constexpr int CS = REG ? 7 : 8;        // log2 of a feature column's bytes
     constexpr int NT = (NWALK + 1) * 64;
@@ -120,8 +120,8 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
             sum[k] = (sums_in && irow < rows) ? sums_in[irow] : 0.0f;
         }
         bool dead = false;
-        for (int t0 = 0; t0 < num_trees && !dead; t0 += kQBatch) {
-            const int nb = min(kQBatch, num_trees - t0);
+        for (int t0 = 0; t0 < num_trees && !dead; t0 += BATCH) {
+            const int nb = min(BATCH, num_trees - t0);
             int spins = 0;
             for (;;) {
                 const bool ok = lane >= nb || lds_flag_load(&ring_ready[(t0 + lane) % RING]) == (uint32_t)(t0 + lane + 1);
@@ -937,15 +937,14 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
     if (s != TAHOE_OK) return s;
     const int wide = qwide_rows(f);  // 0: 128-row tiles; else rows per tile of the wide-row form
     const int trs = q->reg ? 6 : wide == 64 ? 6 : wide == 32 ? 5 : wide == 16 ? 4 : 7;
-    // Region form: 192-row tiles (three chains, 13 walkers) unless 128-row tiles (two chains, 15 walkers) need less time.
-    // Measured on K3 (profiles/r02/tiles_experiment.json): a 192-row tile takes 1.44 x a 128-row tile, i.e. 0.96 of the time
-    // per row -- but 10 k rows run as 79 tiles of 128 on 79 CUs rather than 53 of 192, and 125 k rows as 4 waves of 128-row
-    // tiles (4.0) rather than 3 waves of 192-row tiles (4.3).
+    // Region form: 192-row tiles (three chains, 14 walkers) unless 128-row tiles (two chains, 15 walkers) need less time.
+    // Measured on K3: a 192-row tile takes 1.40 x a 128-row tile, i.e. 0.94 of the time per row -- but 125 k rows run as 4
+    // waves of 128-row tiles (4.0) rather than 3 waves of 192-row tiles (4.2).
     int chains = 2;
     if (q->reg) {
         const size_t cus = (size_t)std::max(f->num_cus, 1);
         const size_t w2 = ((rows + 127) / 128 + cus - 1) / cus, w3 = ((rows + 191) / 192 + cus - 1) / cus;
-        chains = 100 * w2 <= 144 * w3 ? 2 : 3;
+        chains = 100 * w2 <= 140 * w3 ? 2 : 3;
         if (f->knob_qring_chains == 2 || f->knob_qring_chains == 3) chains = f->knob_qring_chains;
     }
     int most = 1;

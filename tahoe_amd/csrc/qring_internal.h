@@ -68,11 +68,13 @@ constexpr int kQBatch = TAHOE_QRING_BATCH;  // trees the consumer takes per poll
 constexpr int kQSpinLimit = 1 << 22;
 constexpr int kQSlotBytes = 4096;            // LDS per walker: a 10-level top (2^10 u32)
 // Region form (NARROW, num_cols <= 256): a tile is K regions of 64 rows, each [fid][64] u16 at a multiple of 32 KiB in LDS.
-// K = 3: 13 walkers x 3 chains and a ring of 15 (96 + 52 + 11.3 KiB); K = 2: 15 walkers x 2 chains, ring of 24.
+// K = 3: 14 walkers x 3 chains and a ring of 10 (96 + 56 + 7.5 KiB = 163,372 B of the 163,840); K = 2: 15 walkers x 2
+// chains, ring of 24.  Throughput follows the walker count (13 walkers / ring 15: 3.80 ms on K3, 14 / 10: 3.71, 15 / 5: 3.73):
+// a ring shorter than the walker count only makes a walker that finishes early wait for the trees before its own.
 constexpr int kRegRows = 64;
 constexpr int kRegBytes = 32768;
-constexpr int kReg3Walkers = 13;
-constexpr int kReg3Ring = 15;
+constexpr int kReg3Walkers = 14;
+constexpr int kReg3Ring = 10;
 constexpr int kQMaxTable = 32767;
 #ifndef TAHOE_QUANT_MAX_SHIFT
 #define TAHOE_QUANT_MAX_SHIFT 16  // K3: 15 -> 0.907 ms, 16 -> 0.874 ms (half the table staging per row)
