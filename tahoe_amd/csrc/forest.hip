@@ -626,7 +626,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
         const int e = t % RING;
 #pragma unroll
         for (int k = 0; k < K; ++k) ring_vals[e * ROWS + k * 64 + lane] = v[k];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("" ::: "memory");  // values before the flag: a wave's LDS operations are performed in issue order
         if (lane == 0) ring_ready[e] = (uint32_t)(t + 1);
         if (more) commit_top();  // this wave's reads of its slot are done (in-order LDS)
     }

@@ -454,7 +454,7 @@ __global__ void __launch_bounds__(16 * 64)
                 }
             }
             if (t < num_trees) ring_vals[(t % RE) * RT + r] = v;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // values before the flags (in-order LDS)
+            asm volatile("" ::: "memory");  // values before the flags: a wave's LDS operations are performed in issue order
             if (r == 0 && t < num_trees) lds_flag_store(&ring_ready[t % RE], (uint32_t)(t + 1));
         };
         int g_p = -1;  // group whose bottom blocks are in flight

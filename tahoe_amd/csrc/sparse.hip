@@ -250,7 +250,7 @@ __global__ void __launch_bounds__(NW * 64) sparse_top_kernel(const uint2 *__rest
         }
         const int e = t % kSRing;
         ring_vals[e * kTileRows + lane] = v;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // values before the flag (in-order LDS)
+        asm volatile("" ::: "memory");  // values before the flag: a wave's LDS operations are performed in issue order
         if (lane == 0) lds_flag_store(&ring_ready[e], (uint32_t)(t + 1));
     }
     if (dead && lane == 0) atomicOr(error_flag, 1);
