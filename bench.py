@@ -129,6 +129,9 @@ def main():
     ap.add_argument("--no-host", action="store_true", help="skip the host-resident (PCIe-inclusive) leg")
     ap.add_argument("--no-k4", "--no-tree-leg", dest="no_k4", action="store_true", help="skip the secondary K4 legs")
     ap.add_argument("--k4-trees", type=int, default=8000)
+    ap.add_argument("--k4-chain", action="store_true",
+                    help="N > 1: also time the chained (bit-exact, point-to-point) tree shards of K4; off by default because a stuck "
+                         "send/recv would take the process group -- and the primary line -- down with it")
     ap.add_argument("--k4-sample", type=int, default=2048, help="rows of the K4 legs checked against the float64 CPU sum")
     args = ap.parse_args()
 
@@ -466,7 +469,7 @@ def k4_legs(args, ta, sharding, torch, coll, dist, world, rank, fence, max_over_
     s_lo, s_hi = sharding.shard_bounds(T4, rank if world > 1 else 0, n_shards)
     fb = ta.Forest(nodes4[s_lo * per_tree: s_hi * per_tree], s_hi - s_lo, D, C, missing=MISSING)
     fb.reserve(R)
-    for mode in (("allreduce64", "chain") if world > 1 else ("allreduce64",)):
+    for mode in (("allreduce64", "chain") if (world > 1 and args.k4_chain) else ("allreduce64",)):
         if world > 1:
             tsf = sharding.TreeShardedForest.__new__(sharding.TreeShardedForest)
             tsf.dist, tsf.group, tsf.rank, tsf.world, tsf.num_trees = coll, None, rank, world, T4
