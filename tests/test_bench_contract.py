@@ -46,3 +46,20 @@ def test_bench_source_keeps_the_oracle_out_of_the_timed_regions():
     assert "oracle" not in primary
     for chunk in src.split("timed(lambda:")[1:]:
         assert "oracle" not in chunk.split("\n")[0]
+
+
+def test_committed_pmc_profile_belongs_to_these_kernel_sources():
+    """roofline.traffic / roofline.physical come from profiles/r02/pmc_k3.json only while its stamp matches the device
+    sources in the tree (bench.kernel_source_hash); a kernel edit without a fresh tools/pmc.sh run turns this red."""
+    import sys
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    prof = json.load(open(os.path.join(ROOT, "profiles", "r02", "pmc_k3.json")))
+    assert prof["src_hash"] == bench.kernel_source_hash()
+    phys = bench.physical_ceilings(prof, 3.7, 0.77, 1_000_000, 256)
+    for kern in ("walk", "quantise"):
+        for key in ("vector_issue_busy", "valu_busy", "lds_busy", "texture_addr_busy", "hbm_frac_counters_raw"):
+            assert 0.0 < phys[kern][key] <= 1.0, (kern, key, phys[kern][key])
+    assert phys["quantise"]["hbm_frac_compulsory"] < 0.5  # the kernel furthest from its HBM roofline, said so
