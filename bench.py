@@ -71,9 +71,13 @@ def physical_ceilings(prof, walk_ms, quant_ms, rows, cols):
     profiled run (ratios inside that run) next to the live kernel times of this one."""
     out = {"source": "profiles/r02/pmc_k3.json", "src_hash": prof["src_hash"]}
     for key, kname in (("walk", "qring"), ("quantise", "quantize")):
-        k = next((v for n, v in prof["kernels"].items() if kname in n and "bucket_index" not in n), None)
-        if not k:
+        parts = [v for n, v in prof["kernels"].items() if kname in n and "bucket_index" not in n]
+        if not parts:
             continue
+        # a step may walk in two launches (waves of 192-row tiles + a 128-row remainder): one launch after the other, so
+        # counters and cycles add up
+        k = {c: sum(part.get(c, 0.0) for part in parts) for c in parts[0]}
+        out.setdefault("kernels_per_step", {})[key] = len(parts)
         cyc = k["GRBM_GUI_ACTIVE"] / 8.0  # shader cycles of one launch (the counter sums the 8 XCDs)
         cus, simds = prof.get("num_cus", 256), prof.get("num_cus", 256) * 4
         vmem = max(k.get("SQ_ACTIVE_INST_VMEM", 0.0), k.get("SQ_INSTS_VMEM_RD", 0.0) + k.get("SQ_INSTS_VMEM_WR", 0.0))

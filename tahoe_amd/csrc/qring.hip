@@ -59,8 +59,10 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                  uint32_t *__restrict__ leaf_out, size_t rows, int cols, int num_trees, int depth, int top_levels,
                  int top_stride, const uint32_t *__restrict__ chunk_flags, int *__restrict__ error_flag,
                  const float *sums_in, int tree_base, int total_trees, int cshift, float *__restrict__ leafbuf, size_t leaf_stride,
-                 int slices)
+                 int slices, size_t row_begin)
 {
+    // `rows` is the END of the rows this launch walks and row_begin (region form only; a multiple of 384) their start: a batch
+    // may be walked as whole waves of 192-row tiles followed by a remainder of 128-row tiles (qring_launch).
     static_assert(!SPLIT || REG, "tree slices are a form of the region kernel");
     static_assert(REG || K == kQRows / 64, "the 128-slot column layout holds exactly two chains");
     static_assert(!REG || (LDSX && NARROW && !EXCH), "regions are a form of the NARROW LDS tile");
@@ -85,7 +87,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
     uint32_t *ring_ready = reinterpret_cast<uint32_t *>(ring_vals + RING * TR);
     uint32_t *consumed = ring_ready + RING;
 
-    const size_t row0 = (size_t)tile_id * TR;
+    const size_t row0 = row_begin + (size_t)tile_id * TR;
     if (LDSX && NARROW && (uint32_t)reinterpret_cast<uintptr_t>(tile) != 0u) {
         // q_xread's v_bfi needs the tile at LDS address 0 (true while the kernel has no static LDS)
         if (tid == 0) atomicOr(error_flag, 2);
@@ -96,7 +98,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
     if (REG) {  // K consecutive regions of the workspace, each to its 32-KiB-aligned place
         const int n16 = cols * kRegRows * 2 / 16;  // 16-byte pieces of a region
         for (int k = 0; k < K; ++k) {
-            const uint4 *src = reinterpret_cast<const uint4 *>(xq + ((size_t)tile_id * K + k) * ((size_t)cols * kRegRows));
+            const uint4 *src = reinterpret_cast<const uint4 *>(xq + ((row0 >> 6) + (size_t)k) * ((size_t)cols * kRegRows));
             uint4 *dst = reinterpret_cast<uint4 *>(smem + (size_t)k * kRegBytes);
             for (int e = tid; e < n16; e += NT) dst[e] = src[e];
         }
@@ -881,10 +883,11 @@ static tahoe_status qring_reserve_leafbuf(tahoe_forest *f, size_t rows, int tree
 template <int NWALK, bool LDSX = true, bool NARROW = false, bool EXCH = false, int K = 2, bool REG = false, int RING = kQRing,
           bool SPLIT = false>
 static void q_launch(tahoe_forest *f, const tahoe_qgroup &g, float *sums, const float *sums_in, uint32_t *leaf_out,
-                     size_t rows, hipStream_t stream, int cshift, int slices = 1)
+                     size_t rows, hipStream_t stream, int cshift, int slices = 1, size_t row_begin = 0)
 {
     tahoe_qstate *q = f->q;
-    const unsigned grid = (unsigned)((rows + 64 * K - 1) / (64 * K)) * (unsigned)(SPLIT ? slices : 1);
+    const unsigned grid = (unsigned)((rows - row_begin + 64 * K - 1) / (64 * K)) * (unsigned)(SPLIT ? slices : 1);
+    if (grid == 0) return;
     float *leafbuf = SPLIT ? q->leafbuf : nullptr;
     const size_t leaf_stride = SPLIT ? q->leaf_stride : 0;
     const int lds = REG ? (int)qreg_lds_for(K, NWALK, RING) : (int)qring_lds_for(f, NWALK, LDSX);
@@ -893,12 +896,12 @@ static void q_launch(tahoe_forest *f, const tahoe_qgroup &g, float *sums, const 
         hipLaunchKernelGGL((qring_kernel<NWALK, true, LDSX, NARROW, EXCH, K, REG, RING, SPLIT>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, g.top,
                            g.blocks, g.qinner, leaf_orig, sums, leaf_out, rows, f->p.num_cols, g.num_trees, f->depth,
                            q->top_levels, q->top_stride, q->chunk_flags, f->error_flag, sums_in, g.tree_lo, f->p.num_trees, cshift, leafbuf, leaf_stride,
-                           slices);
+                           slices, row_begin);
     else
         hipLaunchKernelGGL((qring_kernel<NWALK, false, LDSX, NARROW, EXCH, K, REG, RING, SPLIT>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, g.top,
                            g.blocks, g.qinner, leaf_orig, sums, leaf_out, rows, f->p.num_cols, g.num_trees, f->depth,
                            q->top_levels, q->top_stride, q->chunk_flags, f->error_flag, sums_in, g.tree_lo, f->p.num_trees, cshift, leafbuf, leaf_stride,
-                           slices);
+                           slices, row_begin);
     if (SPLIT && sums)
         hipLaunchKernelGGL(ordered_sum_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, leafbuf, leaf_stride, g.num_trees,
                            sums_in, sums, rows);
@@ -937,15 +940,31 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
     if (s != TAHOE_OK) return s;
     const int wide = qwide_rows(f);  // 0: 128-row tiles; else rows per tile of the wide-row form
     const int trs = q->reg ? 6 : wide == 64 ? 6 : wide == 32 ? 5 : wide == 16 ? 4 : 7;
-    // Region form: 192-row tiles (three chains, 14 walkers) unless 128-row tiles (two chains, 15 walkers) need less time.
-    // Measured on K3: a 192-row tile takes 1.40 x a 128-row tile, i.e. 0.94 of the time per row -- but 125 k rows run as 4
-    // waves of 128-row tiles (4.0) rather than 3 waves of 192-row tiles (4.2).
-    int chains = 2;
+    // Region form: 192-row tiles (three chains, 14 walkers) take 1.40 x the time of 128-row tiles (two chains, 15 walkers),
+    // i.e. 0.94 per row -- but a last, partly filled wave of workgroups costs a whole tile time.  The batch is therefore
+    // walked as n whole waves of 192-row tiles followed by a remainder in whichever form is cheaper, n chosen to minimise
+    // 1.40 n + remainder (125 k rows: 2 waves of 192-row tiles + 209 tiles of 128 = 3.8 instead of 4 waves of 128-row tiles;
+    // 10 k rows: 79 tiles of 128).  Any cut is correct; TAHOE_QRING_CHAINS = 2 / 3 forces one form for the whole batch.
+    size_t rows3 = 0;   // rows [0, rows3) in 192-row tiles, a multiple of 384
+    int chains = 2;     // form of the remaining rows [rows3, rows)
     if (q->reg) {
         const size_t cus = (size_t)std::max(f->num_cus, 1);
-        const size_t w2 = ((rows + 127) / 128 + cus - 1) / cus, w3 = ((rows + 191) / 192 + cus - 1) / cus;
-        chains = 100 * w2 <= 140 * w3 ? 2 : 3;
-        if (f->knob_qring_chains == 2 || f->knob_qring_chains == 3) chains = f->knob_qring_chains;
+        auto waves = [cus](size_t r, size_t tile) { return ((r + tile - 1) / tile + cus - 1) / cus; };
+        if (f->knob_qring_chains == 2 || f->knob_qring_chains == 3) {
+            chains = f->knob_qring_chains;
+        } else {
+            size_t best = SIZE_MAX;
+            for (size_t n = 0; n <= waves(rows, 192); ++n) {
+                const size_t r3 = std::min(rows, n * cus * 192 / 384 * 384), rem = rows - r3;
+                const size_t c2 = 100 * waves(rem, 128), c3 = 140 * waves(rem, 192);
+                const size_t cost = 140 * waves(r3, 192) + std::min(c2, c3);
+                if (cost < best) {
+                    best = cost;
+                    rows3 = rem ? r3 : 0;               // a pure 192-row plan is "no first part, remainder in form 3"
+                    chains = rem ? (c2 <= c3 ? 2 : 3) : 3;
+                }
+            }
+        }
     }
     int most = 1;
     const int slices = q_slices(f, rows, &most);  // small batches of the region form: tree slices per tile (SPLIT)
@@ -953,6 +972,7 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
         const tahoe_status ls = qring_reserve_leafbuf(f, rows, most);  // no-op after tahoe_forest_reserve / a first predict
         if (ls != TAHOE_OK) return ls;
         chains = 2;
+        rows3 = 0;
     }
     bool first = true;
     for (const tahoe_qgroup &g : q->groups) {  // stream order: quantise for the group, walk the group, next group
@@ -978,10 +998,15 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
             case 15:
                 if (q->reg && slices > 1)
                     q_launch<15, true, true, false, 2, true, kQRing, true>(f, g, sums, sums_in, leaf_out, rows, stream, cshift, slices);
-                else if (q->reg && chains == 3)
-                    q_launch<kReg3Walkers, true, true, false, 3, true, kReg3Ring>(f, g, sums, sums_in, leaf_out, rows, stream, cshift);
-                else if (q->reg)
-                    q_launch<15, true, true, false, 2, true>(f, g, sums, sums_in, leaf_out, rows, stream, cshift);
+                else if (q->reg) {
+                    if (rows3 > 0)
+                        q_launch<kReg3Walkers, true, true, false, 3, true, kReg3Ring>(f, g, sums, sums_in, leaf_out, rows3, stream, cshift);
+                    if (chains == 3)
+                        q_launch<kReg3Walkers, true, true, false, 3, true, kReg3Ring>(f, g, sums, sums_in, leaf_out, rows, stream, cshift, 1,
+                                                                                      rows3);
+                    else
+                        q_launch<15, true, true, false, 2, true>(f, g, sums, sums_in, leaf_out, rows, stream, cshift, 1, rows3);
+                }
                 else if (q->narrow && f->relayout)
                     q_launch<15, true, true, true>(f, g, sums, sums_in, leaf_out, rows, stream, cshift);
                 else if (q->narrow)

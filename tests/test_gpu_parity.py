@@ -333,6 +333,32 @@ def test_region_form_two_and_three_chains(env, monkeypatch):
             monkeypatch.delenv(k)
 
 
+def test_batches_walked_as_waves_of_192_row_tiles_plus_a_128_row_remainder(env):
+    """Mid-size batches of the region form run as whole waves of 192-row tiles followed by a remainder of 128-row tiles
+    (two launches over disjoint row ranges; 125 k rows on 256 CUs: 98,304 + 26,696).  Every row against the oracle, leaf
+    indices on the rows around the cut, running sums continued across it."""
+    ta, oracle, torch = env
+    T, D, C, R = 30, 8, 64, 300_000
+    nodes = ta.synth_forest(T, D, C, seed=95, leaf_prob=0.02)
+    data = ta.synth_data(R, C, seed=96, missing_prob=0.0002, missing=MISSING)
+    want, _ = oracle.predict(nodes, T, D, data, MISSING, threads=8)
+    x = torch.from_numpy(data).cuda()
+    forest = ta.Forest(nodes, T, D, C, missing=MISSING)
+    forest.set_strategy(ta.STRATEGY_QRING)
+    for rows in (110_000, 125_000, 147_457, 250_000, R):
+        got = forest.predict_raw(x[:rows].contiguous())
+        forest.check()
+        assert np.array_equal(bits(got.cpu().numpy()), bits(want[:rows])), rows
+    lo, hi = 98_304 - 300, 98_304 + 300  # around the cut of the 125 k-row plan
+    _, want_leaf = oracle.predict(nodes, T, D, data[lo:hi], MISSING, want_leaf=True)
+    leaf, _ = forest.predict_leaf_idx(x[:125_000].contiguous(), want_sums=False)
+    assert np.array_equal(bits(leaf[lo:hi].cpu().numpy()), want_leaf)
+    start = np.linspace(-1, 1, 125_000).astype(np.float32)
+    cont = oracle.predict_continue(nodes, T, D, data[:125_000], MISSING, start.copy(), threads=8)
+    got = forest.predict_accumulate(x[:125_000].contiguous(), torch.from_numpy(start.copy()).cuda())
+    assert np.array_equal(bits(got.cpu().numpy()), bits(cont))
+
+
 def test_small_batches_walked_in_tree_slices(env, monkeypatch):
     """QRING's SPLIT form (the counterpart of the reference's split-forest strategy idx 4): a batch with fewer tiles than CUs
     gives every tile to several workgroups, each a slice of the trees, and a second kernel adds the leaf values per row in
