@@ -47,12 +47,19 @@ def algorithmic_bytes_per_sample(T, depth, cols, bits_bytes):
 
 
 def kernel_source_hash():
-    """Identifies the kernels a profile was taken with: sha256 over the device sources."""
+    """Identifies the kernels a profile was taken with: sha256 over the device sources, comments and white space
+    removed (an edit of a comment does not make a profile stale)."""
+    import re
+
     h = hashlib.sha256()
     for path in sorted(glob.glob(os.path.join(ROOT, "tahoe_amd", "csrc", "*.hip")) +
                        glob.glob(os.path.join(ROOT, "tahoe_amd", "csrc", "*.h"))):
-        with open(path, "rb") as fh:
-            h.update(os.path.basename(path).encode() + b"\0" + fh.read())
+        with open(path, "r", errors="replace") as fh:
+            text = fh.read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", "", text)
+        text = re.sub(r"\s+", " ", text)
+        h.update(os.path.basename(path).encode() + b"\0" + text.encode())
     return h.hexdigest()[:16]
 
 

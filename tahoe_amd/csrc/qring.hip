@@ -17,11 +17,19 @@
 // Rows too wide for a 128-row tile (num_cols > ~550) use 64 / 32 / 16-row tiles with several trees per wave
 // (qwide_kernel); only beyond ~4500 columns are feature codes read from the quantised tile in L2 (GX form).
 //
-// Per predict: (1) quantize.hip turns the row-major float32 batch into tiles xq[tile][fid][128] u16 (rows
+// Per predict: (1) quantize.hip turns the row-major float32 batch into u16 codes in the walk's LDS order (rows
 // permuted inside a column so that lane = row reads are bank-conflict free); (2) qring_kernel walks: per CU one
-// workgroup = NWALK walker waves (private top slot each, two 64-row chains per lane, next top
+// workgroup = NWALK walker waves (private top slot each, K 64-row chains per lane, next top
 // prefetched in registers, no barrier in the tree loop) + one consumer wave that adds the leaf values
 // in tree order through an LDS ring -- the float32 sums stay bit-identical to predict_on_cpu.
+// Forms of the walk, picked at create (node layout) and per batch (qring_launch):
+//   region form (num_cols <= 256; what K3 runs)  codes as 64-row regions xq[row / 64][fid][64]; a tile is three regions
+//       (192 rows, 14 walkers, ring of 10) or two (128 rows, 15 walkers, ring of 24); a batch runs as whole waves of 192-row
+//       tiles plus a remainder in the cheaper form; small batches give every tile to several workgroups, each a slice of
+//       the trees (SPLIT) followed by ordered_sum_kernel
+//   128-slot columns xq[tile][fid][128]          the general node layout (num_cols <= ~550), the exchange-bit layout
+//       of the probability-guided re-layout, and the GX form (features read from L2)
+//   wide rows (qwide_kernel)                      64 / 32 / 16-row tiles, several trees per wave
 //
 // Replaces, like forest.hip: the adaptive-format walkers/kernels of Struct.h:953-1704 and the
 // layout build of Struct.h:1756-1986 (whose char/short/int "adaptive" widths compress only the
