@@ -36,13 +36,15 @@
 // fid/flag word; here the threshold is compressed too, losslessly).
 #include "qring_internal.h"
 
-// s_sleep arguments of the two spin loops (consumer polling ready flags, walker waiting for ring space): 1..16 all
-// within 1.5 % on K3; raising the consumer wave's priority (s_setprio) likewise
+// s_sleep arguments of the two spin loops (consumer polling ready flags, walker waiting for ring space).  With the 192-row
+// tile's ring of 10 for 14 walkers a finished walker does wait for ring space: walker sleep 4 / 8 / 16 / 32 / 64 -> 3.66 / 3.62 /
+// 3.60 / 3.70 / 5.10 ms on K3; consumer sleep 1 / 4 / 8 -> 3.645 / 3.657 / 3.669.  Raising the consumer wave's priority
+// (s_setprio): no difference.
 #ifndef TAHOE_CONS_SLEEP
-#define TAHOE_CONS_SLEEP 4
+#define TAHOE_CONS_SLEEP 1
 #endif
 #ifndef TAHOE_WALK_SLEEP
-#define TAHOE_WALK_SLEEP 4
+#define TAHOE_WALK_SLEEP 16
 #endif
 
 namespace tahoe {
