@@ -169,13 +169,17 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
     uint32_t *slot = reinterpret_cast<uint32_t *>(slots + (size_t)wave * slot_bytes);
     const int n_chunks = (top_stride * 4) >> 4;  // 16-byte chunks of a top in global memory (<= 256)
     uint4 pf0 = {}, pf1 = {}, pf2 = {}, pf3 = {};   // named registers (an indexed array would go to scratch)
+    // byte offsets of this lane's four 16-byte chunks inside a top (clamped: branch-free and in bounds), computed once:
+    // the loads then take the tree's base from SGPRs and a 32-bit offset from a VGPR, no per-tree address arithmetic
+    const uint32_t last_chunk = (uint32_t)(n_chunks - 1);
+    const uint32_t po0 = 16u * min((uint32_t)(0 * 64 + lane), last_chunk), po1 = 16u * min((uint32_t)(1 * 64 + lane), last_chunk);
+    const uint32_t po2 = 16u * min((uint32_t)(2 * 64 + lane), last_chunk), po3 = 16u * min((uint32_t)(3 * 64 + lane), last_chunk);
     auto prefetch_top = [&](int t) {
-        const uint4 *g = reinterpret_cast<const uint4 *>(top + (size_t)t * top_stride);
-        const int last = n_chunks - 1;  // clamped: branch-free and in bounds
-        pf0 = g[min(0 * 64 + lane, last)];
-        pf1 = g[min(1 * 64 + lane, last)];
-        pf2 = g[min(2 * 64 + lane, last)];
-        pf3 = g[min(3 * 64 + lane, last)];
+        const unsigned char *g = reinterpret_cast<const unsigned char *>(top + (size_t)t * top_stride);
+        pf0 = *reinterpret_cast<const uint4 *>(g + po0);
+        pf1 = *reinterpret_cast<const uint4 *>(g + po1);
+        pf2 = *reinterpret_cast<const uint4 *>(g + po2);
+        pf3 = *reinterpret_cast<const uint4 *>(g + po3);
     };
     // Unconditional stores (a smaller top just rewrites its last chunk into unused slot space): with
     // per-lane conditions hipcc branches around each store AND its s_waitcnt, leaves the load "pending" on
@@ -305,7 +309,9 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
             t_p = t;
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                const uint4 *bp = blocks + ((size_t)t * n_blocks + bsel[k]) * 2;
+                // the tree's blocks from SGPRs, the block's byte offset (32 bits) from a VGPR
+                const unsigned char *tb = reinterpret_cast<const unsigned char *>(blocks + (size_t)t * n_blocks * 2);
+                const uint4 *bp = reinterpret_cast<const uint4 *>(tb + 32u * bsel[k]);
                 na_p[k] = bp[0];  // node0, node1, node2, 0
                 nb_p[k] = bp[1];  // four leaf values
                 bsel_p[k] = bsel[k];
