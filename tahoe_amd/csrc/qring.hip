@@ -267,7 +267,21 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                 // Both children come with one ds_read_b64 issued beside the feature read, ahead of the compare.  (Reading
                 // only the chosen child afterwards -- half the LDS bytes, twice the round trips -- times the same to
                 // 0.5 %: neither LDS bandwidth nor LDS latency bounds this loop, see DESIGN.md.)
-                for (int l = 0; l < top_levels - 1; ++l) {
+                int l0 = 0;
+                if (top_levels > 1) {  // level 0: every chain is at the root -- one read of its child pair serves them all
+                    const uint2 pr0 = *reinterpret_cast<const uint2 *>(&slot[2]);
+                    uint32_t xc0[K];
+    #pragma unroll
+                    for (int k = 0; k < K; ++k) xc0[k] = q_xread<LDSX, NARROW, CS>(gx, node[k], pos[k]);
+    #pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const uint64_t cm = q_right_mask<MS, NARROW, EXCH>(xc0[k], node[k]);
+                        i[k] = q_descend(i[k], cm);
+                        node[k] = __builtin_amdgcn_inverse_ballot_w64(cm) ? pr0.y : pr0.x;
+                    }
+                    l0 = 1;
+                }
+                for (int l = l0; l < top_levels - 1; ++l) {
                     uint32_t xc[K];
                     uint2 pr[K];
     #pragma unroll
