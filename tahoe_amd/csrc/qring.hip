@@ -970,10 +970,10 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
     if (s != TAHOE_OK) return s;
     const int wide = qwide_rows(f);  // 0: 128-row tiles; else rows per tile of the wide-row form
     const int trs = q->reg ? 6 : wide == 64 ? 6 : wide == 32 ? 5 : wide == 16 ? 4 : 7;
-    // Region form: 192-row tiles (three chains, 14 walkers) take 1.40 x the time of 128-row tiles (two chains, 15 walkers),
-    // i.e. 0.94 per row -- but a last, partly filled wave of workgroups costs a whole tile time.  The batch is therefore
+    // Region form: 192-row tiles (three chains, 14 walkers) take 1.33 x the time of 128-row tiles (two chains, 15 walkers),
+    // i.e. 0.89 per row -- but a last, partly filled wave of workgroups costs a whole tile time.  The batch is therefore
     // walked as n whole waves of 192-row tiles followed by a remainder in whichever form is cheaper, n chosen to minimise
-    // 1.40 n + remainder (125 k rows: 2 waves of 192-row tiles + 209 tiles of 128 = 3.8 instead of 4 waves of 128-row tiles;
+    // 1.33 n + remainder (125 k rows: 2 waves of 192-row tiles + 209 tiles of 128 = 3.8 instead of 4 waves of 128-row tiles;
     // 10 k rows: 79 tiles of 128).  Any cut is correct; TAHOE_QRING_CHAINS = 2 / 3 forces one form for the whole batch.
     size_t rows3 = 0;   // rows [0, rows3) in 192-row tiles, a multiple of 384
     int chains = 2;     // form of the remaining rows [rows3, rows)
@@ -986,8 +986,8 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
             size_t best = SIZE_MAX;
             for (size_t n = 0; n <= waves(rows, 192); ++n) {
                 const size_t r3 = std::min(rows, n * cus * 192 / 384 * 384), rem = rows - r3;
-                const size_t c2 = 100 * waves(rem, 128), c3 = 140 * waves(rem, 192);
-                const size_t cost = 140 * waves(r3, 192) + std::min(c2, c3);
+                const size_t c2 = 100 * waves(rem, 128), c3 = 133 * waves(rem, 192);
+                const size_t cost = 133 * waves(r3, 192) + std::min(c2, c3);
                 if (cost < best) {
                     best = cost;
                     rows3 = rem ? r3 : 0;               // a pure 192-row plan is "no first part, remainder in form 3"
