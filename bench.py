@@ -538,8 +538,9 @@ def k4_legs(args, ta, sharding, torch, coll, dist, world, rank, fence, max_over_
             "row_shard_ms_over_tree_shard_ms": round(t_rows / t_trees, 3),
             "why": "row shards are bit-exact and need no collective; the all-reduce of tree-shard totals is not within 1e-6 "
                    "relative of the CPU's sequential float32 sum (max_rel_diff_vs_cpu_f32), the bit-exact chain pays (N - 1) chunk "
-                   "times of pipeline fill; kernel time per rank is within a few per cent either way (one rank's R/8 rows of the "
-                   "whole forest: four tree groups, 3.8 waves of tiles -- against all R rows of a 1/8 forest, all-reduce not counted)"}
+                   "times of pipeline fill; the price of rows is row_shard_ms_over_tree_shard_ms in kernel time per rank (one rank's R/8 "
+                   "rows of the whole forest: four tree groups, each with its own quantise pass -- against all R rows of a 1/8 forest, "
+                   "all-reduce not counted)"}
     fb.close()
     return legs
 
