@@ -201,8 +201,10 @@ tahoe_status tahoe_forest_set_strategy(tahoe_forest *f, int strategy);
  * LDS wait of TILERING timing out); TAHOE_OK otherwise. */
 tahoe_status tahoe_forest_check(tahoe_forest *f, void *stream);
 /* Sizes the handle's device workspace for batches of up to `rows` rows (QRING keeps a 2-byte-per-value
- * quantised copy of the batch).  Optional: predict grows the workspace on demand, which is the only
- * case in which a predict call allocates (and synchronises the device). */
+ * quantised copy of the batch and, for the batches small enough to be walked in tree slices -- up to
+ * 64 rows per CU -- one float per (tree of the largest group, row)).  Optional: predict grows the
+ * workspace on demand, which is the only case in which a predict call allocates (and synchronises the
+ * device); after reserve(rows) no batch of up to `rows` rows does. */
 tahoe_status tahoe_forest_reserve(tahoe_forest *f, size_t rows);
 
 /* Host-resident batch (the reference uploads the data file once, BaseTahoeTest.h:378-389, and

@@ -863,13 +863,25 @@ tahoe_status qring_reserve(tahoe_forest *f, size_t rows)
         TAHOE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&q->xq), bytes));
         q->xq_rows = tiles * kQRows;
         f->device_bytes += bytes;
-        if (q->chunk_flags) TAHOE_HIP_TRY(hipFree(q->chunk_flags));
+        if (q->chunk_flags) (void)hipFree(q->chunk_flags);
         q->chunk_flags = nullptr;
         q->n_chunk_flags = (q->xq_rows + kQuantMinRowsPerBlock - 1) / kQuantMinRowsPerBlock + 1;
-        TAHOE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&q->chunk_flags), q->n_chunk_flags * sizeof(uint32_t)));
+        const hipError_t e = hipMalloc(reinterpret_cast<void **>(&q->chunk_flags), q->n_chunk_flags * sizeof(uint32_t));
+        if (e != hipSuccess) {  // all or nothing: the next reserve starts over
+            q->chunk_flags = nullptr;
+            (void)hipFree(q->xq);
+            f->device_bytes -= bytes;
+            q->xq = nullptr;
+            q->xq_rows = 0;
+            return fail(TAHOE_ERR_HIP, "qring_reserve: hipMalloc failed: %s", hipGetErrorString(e));
+        }
     }
-    int most = 1;  // a batch small enough to be walked in tree slices also needs the leaf-value buffer
-    if (q_slices(f, rows, &most) > 1) return qring_reserve_leafbuf(f, rows, most);
+    // Batches small enough to be walked in tree slices (SPLIT) also need the leaf-value buffer.  Every batch of up to `rows`
+    // rows must find it in place -- also a small one after a large reserve -- so it is sized for the largest split batch
+    // that fits in `rows` (slices fall to 1 once the 128-row tiles outnumber half the CUs).
+    int most = 1;
+    const size_t split_max = f->knob_qring_slices >= 1 ? rows : std::min<size_t>(rows, (size_t)std::max(f->num_cus, 2) / 2 * 128);
+    if (q_slices(f, split_max, &most) > 1) return qring_reserve_leafbuf(f, split_max, most);
     return TAHOE_OK;
 }
 
