@@ -79,27 +79,35 @@ def main():
         tc = time.perf_counter()
         f = ta.Forest(nodes, T, D, C, missing=MISSING)
         create_s = time.perf_counter() - tc
-        ms, full = time_predict(f, x, steps=3, warmup=1)
+        ms, full = time_predict(f, x, steps=10, warmup=3)
         entry = {"shape": [T, D, C, R], "strategy": ta.STRATEGY_NAMES[f.get_strategy(R)], "ms": round(ms, 3),
                  "create_s": round(create_s, 2), "device_MB": round(f.info().device_bytes / 1e6, 1),
                  "samples_per_s": round(R / ms * 1e3), "parity_sample_%d" % sample.size: check_dense(f, nodes, T, D, data, x, sample)}
         if name == "K4":
             per = ta.capi.tree_num_nodes(D)
-            total = torch.zeros(R, dtype=torch.float32, device="cuda")
+            from tahoe_amd import sharding
+            total = torch.zeros(R, dtype=torch.float64, device="cuda")   # "allreduce64": exact sum of the float32 partials
+            chain = torch.zeros(R, dtype=torch.float32, device="cuda")   # "chain": running float32 sums, shard to shard
             shard_ms = []
             for k in range(8):
                 lo, hi = T * k // 8, T * (k + 1) // 8
                 fs = ta.Forest(nodes[lo * per: hi * per], hi - lo, D, C, missing=MISSING)
                 m, part = time_predict(fs, x, steps=2, warmup=1)
                 shard_ms.append(m)
-                total += part  # what the all-reduce computes, in rank order
+                total += part.double()
+                fs.predict_accumulate(x, chain)
+                fs.check()
                 fs.close()
             exact = oracle.predict_f64(nodes, T, D, data[sample], MISSING)
-            got = total.cpu().numpy()[sample]
+            got = total.float().cpu().numpy()[sample]  # one rounding
+            one = full.cpu().numpy()[sample]
+            bound = sharding.sum_error_bound(oracle.abs_leaf_sum(nodes, T, D, data[sample], MISSING), exact, T // 8)
             entry["tree_shards_8"] = {"ms_per_shard_avg": round(float(np.mean(shard_ms)), 3),
-                                      "max_abs_err_vs_f64": float(np.max(np.abs(got - exact))),
-                                      "max_rel_err_vs_1gpu_f32": float(np.max(np.abs(got - full.cpu().numpy()[sample])
-                                                                              / np.maximum(np.abs(got), 1e-30)))}
+                                      "allreduce64_max_abs_err_vs_f64": float(np.max(np.abs(got - exact))),
+                                      "allreduce64_within_bound": bool(np.all(np.abs(got - exact) <= bound)),
+                                      "one_gpu_f32_max_abs_err_vs_f64": float(np.max(np.abs(one - exact))),
+                                      "allreduce64_max_rel_diff_vs_1gpu_f32": float(np.max(np.abs(got - one) / np.maximum(np.abs(one), 1e-30))),
+                                      "chain_bit_equal_to_1gpu_all_rows": bool(torch.equal(chain.view(torch.int32), full.view(torch.int32)))}
         res[name] = entry
         f.close()
     del x
