@@ -117,7 +117,7 @@ enum {
 };
 /* On a sparse handle (tahoe_sparse_forest_create): DIRECT = nodes and features from global memory,
  * ROWTILE = 64-row float32 tile in LDS, TILEBLOCK = tile + the first 512 nodes of each tree (breadth-first)
- * in LDS, walker waves + ordered ring consumer (AUTO's choice when trees have <= 65536 nodes). */
+ * in LDS, walker waves + ordered ring consumer (AUTO's choice when trees have <= 65535 nodes). */
 
 typedef struct tahoe_forest tahoe_forest; /* opaque */
 

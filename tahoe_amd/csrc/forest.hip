@@ -699,9 +699,15 @@ static int tilering_rows(const tahoe_forest *f)
 
 static int resolve_strategy(const tahoe_forest *f, size_t /*rows*/)
 {
-    if (f->sp) {  // sparse handle: TILEBLOCK = 64-row tile + tree tops in LDS, ROWTILE = tile only, DIRECT = neither
+    if (f->sp) {  // sparse handle: QRING = quantised 192-row tile + tree tops in LDS, TILEBLOCK = 64-row float32 tile + tree
+                  // tops, ROWTILE = tile only, DIRECT = neither
         if (f->strategy == TAHOE_STRATEGY_DIRECT) return TAHOE_STRATEGY_DIRECT;
         if (f->strategy == TAHOE_STRATEGY_ROWTILE) return TAHOE_STRATEGY_ROWTILE;
+        // the quantise pass over rows x cols pays when there is walking to do per feature value (the dense rule, with ten
+        // levels standing in for the unknown path length)
+        if (sparse_q_available(f) &&
+            (f->strategy == TAHOE_STRATEGY_QRING || (f->strategy == TAHOE_STRATEGY_AUTO && 20LL * f->p.num_trees >= 13LL * f->p.num_cols)))
+            return TAHOE_STRATEGY_QRING;
         if (sparse_top_waves(f) > 0) return TAHOE_STRATEGY_TILEBLOCK;
         return sparse_tile_fits(f) ? TAHOE_STRATEGY_ROWTILE : TAHOE_STRATEGY_DIRECT;
     }
@@ -1227,11 +1233,13 @@ tahoe_status tahoe_forest_set_strategy(tahoe_forest *f, int strategy)
     if (strategy < TAHOE_STRATEGY_AUTO || strategy > TAHOE_STRATEGY_QRING)
         return fail(TAHOE_ERR_INVALID_ARG, "unknown strategy %d", strategy);
     if (f->sp) {
-        if (strategy > TAHOE_STRATEGY_TILEBLOCK || (strategy == TAHOE_STRATEGY_ROWTILE && !sparse_tile_fits(f)) ||
-            (strategy == TAHOE_STRATEGY_TILEBLOCK && sparse_top_waves(f) == 0))
+        if ((strategy > TAHOE_STRATEGY_TILEBLOCK && strategy != TAHOE_STRATEGY_QRING) ||
+            (strategy == TAHOE_STRATEGY_ROWTILE && !sparse_tile_fits(f)) ||
+            (strategy == TAHOE_STRATEGY_TILEBLOCK && sparse_top_waves(f) == 0) ||
+            (strategy == TAHOE_STRATEGY_QRING && !sparse_q_available(f)))
             return fail(TAHOE_ERR_UNSUPPORTED,
-                        "a sparse forest runs AUTO, DIRECT, ROWTILE (a 64-row tile fits LDS) or TILEBLOCK (tile + tree tops in LDS; "
-                        "trees of <= 65536 nodes, num_cols <= 32767)");
+                        "a sparse forest runs AUTO, DIRECT, ROWTILE (a 64-row tile fits LDS), TILEBLOCK (tile + tree tops in LDS; "
+                        "trees of <= 65535 nodes, num_cols <= 32767) or QRING (quantised tile + tree tops; also num_cols <= 256)");
         f->strategy = strategy;
         return TAHOE_OK;
     }

@@ -142,6 +142,7 @@ bool sparse_tile_fits(const tahoe_forest *f);
 tahoe_status sparse_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, const float *data, size_t rows,
                            hipStream_t stream, int strategy, const float *sums_in = nullptr);
 int sparse_top_waves(const tahoe_forest *f);
+bool sparse_q_available(const tahoe_forest *f);  // the walk on quantised codes (strategy QRING on a sparse handle)
 void sparse_destroy(tahoe_forest *f);
 void pipeline_destroy(tahoe_forest *f);
 

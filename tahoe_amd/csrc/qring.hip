@@ -556,12 +556,6 @@ __global__ void __launch_bounds__(256) ordered_sum_kernel(const float *__restric
     sums[row] = sum;
 }
 
-// LDS of the region form: K regions of 32 KiB, walker slots, ring
-static long long qreg_lds_for(int k, int nwalk, int ring)
-{
-    return (long long)k * kRegBytes + (long long)nwalk * kQSlotBytes + (long long)ring * k * kRegRows * 4 + (ring + 1) * 4LL;
-}
-
 static long long qring_lds_for(const tahoe_forest *f, int nwalk, bool lds_tile = true)
 {
     return (lds_tile ? (long long)f->p.num_cols * kQRows * 2 : 0) + (long long)nwalk * kQSlotBytes +
@@ -893,7 +887,7 @@ static int q_slices(const tahoe_forest *f, size_t rows, int *most_out)
     int most = 1;
     for (const tahoe_qgroup &g : q->groups) most = std::max(most, g.num_trees);
     *most_out = most;
-    if (!q->reg || rows == 0) return 1;
+    if (!q->reg || q->sparse || rows == 0) return 1;
     const size_t tiles = (rows + 127) / 128;
     const int fit = (int)std::min<size_t>((size_t)std::max(f->num_cus, 1) / tiles, 8);
     int slices = std::max(1, std::min(fit, most / (4 * 15)));
@@ -982,32 +976,9 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
     if (s != TAHOE_OK) return s;
     const int wide = qwide_rows(f);  // 0: 128-row tiles; else rows per tile of the wide-row form
     const int trs = q->reg ? 6 : wide == 64 ? 6 : wide == 32 ? 5 : wide == 16 ? 4 : 7;
-    // Region form: 192-row tiles (three chains, 14 walkers) take 1.33 x the time of 128-row tiles (two chains, 15 walkers),
-    // i.e. 0.89 per row -- but a last, partly filled wave of workgroups costs a whole tile time.  The batch is therefore
-    // walked as n whole waves of 192-row tiles followed by a remainder in whichever form is cheaper, n chosen to minimise
-    // 1.33 n + remainder (125 k rows: 2 waves of 192-row tiles + 209 tiles of 128 = 3.8 instead of 4 waves of 128-row tiles;
-    // 10 k rows: 79 tiles of 128).  Any cut is correct; TAHOE_QRING_CHAINS = 2 / 3 forces one form for the whole batch.
     size_t rows3 = 0;   // rows [0, rows3) in 192-row tiles, a multiple of 384
     int chains = 2;     // form of the remaining rows [rows3, rows)
-    if (q->reg) {
-        const size_t cus = (size_t)std::max(f->num_cus, 1);
-        auto waves = [cus](size_t r, size_t tile) { return ((r + tile - 1) / tile + cus - 1) / cus; };
-        if (f->knob_qring_chains == 2 || f->knob_qring_chains == 3) {
-            chains = f->knob_qring_chains;
-        } else {
-            size_t best = SIZE_MAX;
-            for (size_t n = 0; n <= waves(rows, 192); ++n) {
-                const size_t r3 = std::min(rows, n * cus * 192 / 384 * 384), rem = rows - r3;
-                const size_t c2 = 100 * waves(rem, 128), c3 = 133 * waves(rem, 192);
-                const size_t cost = 133 * waves(r3, 192) + std::min(c2, c3);
-                if (cost < best) {
-                    best = cost;
-                    rows3 = rem ? r3 : 0;               // a pure 192-row plan is "no first part, remainder in form 3"
-                    chains = rem ? (c2 <= c3 ? 2 : 3) : 3;
-                }
-            }
-        }
-    }
+    if (q->reg) qreg_plan(rows, f->num_cus, f->knob_qring_chains, &rows3, &chains);  // TAHOE_QRING_CHAINS = 2 / 3 forces one form
     int most = 1;
     const int slices = q_slices(f, rows, &most);  // small batches of the region form: tree slices per tile (SPLIT)
     if (slices > 1) {

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -41,6 +42,7 @@ struct tahoe_qstate {
     int top_stride = 0;           // u32 entries per tree in `top` (>= 4)
     bool narrow = false;          // node words in the NARROW layout (num_cols <= 256, 15 walkers, LDS tile)
     bool reg = false;             // ... in its region form: fid << 7, tiles of two or three 64-row regions (qring.hip)
+    bool sparse = false;          // the handle is a sparse forest: tables, workspace and region tiles only (sparse.hip walks)
     int wide_rt = 0;              // rows per tile of the wide-row form (qwide_kernel), fixed at create; 0 = not used
     int wide_lw = 0;              // ... and the top levels its LDS slots hold
     std::vector<tahoe_qgroup> groups;
@@ -76,6 +78,39 @@ constexpr int kRegBytes = 32768;
 constexpr int kReg3Walkers = 14;
 constexpr int kReg3Ring = 10;
 constexpr int kQMaxTable = 32767;
+// LDS of the region form: K regions of 32 KiB, walker slots, ring
+inline long long qreg_lds_for(int k, int nwalk, int ring)
+{
+    return (long long)k * kRegBytes + (long long)nwalk * kQSlotBytes + (long long)ring * k * kRegRows * 4 + (ring + 1) * 4LL;
+}
+// Region form: 192-row tiles (three chains, 14 walkers) take 1.33 x the time of 128-row tiles (two chains, 15 walkers),
+// i.e. 0.89 per row -- but a last, partly filled wave of workgroups costs a whole tile time.  A batch is therefore
+// walked as n whole waves of 192-row tiles followed by a remainder in whichever form is cheaper, n chosen to minimise
+// 1.33 n + remainder (125 k rows: 2 waves of 192-row tiles + 209 tiles of 128 = 3.8 instead of 4 waves of 128-row tiles;
+// 10 k rows: 79 tiles of 128).  Any cut is correct.  *rows3 = rows [0, rows3) in 192-row tiles (a multiple of 384),
+// *chains = form of the remaining rows [rows3, rows).  `force` = 2 / 3: one form for the whole batch.
+inline void qreg_plan(size_t rows, int num_cus, int force, size_t *rows3, int *chains)
+{
+    *rows3 = 0;
+    *chains = 2;
+    const size_t cus = (size_t)std::max(num_cus, 1);
+    auto waves = [cus](size_t r, size_t tile) { return ((r + tile - 1) / tile + cus - 1) / cus; };
+    if (force == 2 || force == 3) {
+        *chains = force;
+        return;
+    }
+    size_t best = SIZE_MAX;
+    for (size_t n = 0; n <= waves(rows, 192); ++n) {
+        const size_t r3 = std::min(rows, n * cus * 192 / 384 * 384), rem = rows - r3;
+        const size_t c2 = 100 * waves(rem, 128), c3 = 133 * waves(rem, 192);
+        const size_t cost = 133 * waves(r3, 192) + std::min(c2, c3);
+        if (cost < best) {
+            best = cost;
+            *rows3 = rem ? r3 : 0;               // a pure 192-row plan is "no first part, remainder in form 3"
+            *chains = rem ? (c2 <= c3 ? 2 : 3) : 3;
+        }
+    }
+}
 #ifndef TAHOE_QUANT_MAX_SHIFT
 #define TAHOE_QUANT_MAX_SHIFT 16  // K3: 15 -> 0.907 ms, 16 -> 0.874 ms (half the table staging per row)
 #endif

@@ -20,18 +20,22 @@
 #include <new>
 #include <vector>
 
-#include "forest_internal.h"
+#include "qring_internal.h"
 
 struct tahoe_sstate {
     tahoe_sparse_node *nodes = nullptr;  // device copy, as given
     int32_t *trees = nullptr;            // device: root offset per tree
     size_t num_nodes = 0;
     int max_tree_nodes = 0;
-    // compact breadth-first copy for sparse_top_kernel (null when a tree has > 65536 reachable nodes or
+    // compact breadth-first copy for sparse_top_kernel (null when a tree has > 65535 reachable nodes or
     // num_cols > 32767): 8-byte nodes, every tree starts on a 16-byte boundary
-    uint2 *cnodes = nullptr;    // x = value bits; y = left_idx << 16 | def_left << 15 | fid, left_idx == 0 <=> leaf
+    uint2 *cnodes = nullptr;    // x = value bits; y = left_idx << 16 | def_left << 15 | fid, left_idx == 0 <=> leaf; root at 1, pairs even
     int32_t *ctrees = nullptr;  // [T + 1] offsets into cnodes (even)
     uint32_t *corig = nullptr;  // compact position -> index relative to the root in the caller's numbering
+    // quantised copy of the compact form for sparse_q_kernel (null when num_cols > 256 or a single tree exceeds the code
+    // range): same positions as cnodes; inner node x = code << 16 | fid << 7 | def_left, y = left position; leaf x = value
+    // bits, y = 0.  The threshold tables, the code workspace and the tree groups live in f->q (qring_internal.h).
+    uint2 *qnodes = nullptr;
 };
 
 namespace tahoe {
@@ -219,21 +223,25 @@ __global__ void __launch_bounds__(NW * 64) sparse_top_kernel(const uint2 *__rest
         commit_top();  // own slot, own wave: LDS operations of one wave complete in order
         if (t + NWALK < num_trees) prefetch_top(t + NWALK);
         const uint2 *root = cnodes + ctrees[t];
-        uint32_t curr = 0;
+        uint32_t curr = 1u;  // the root; position 0 is padding
+        uint2 n = slot[1];
         float v;
         for (;;) {  // create() guarantees children after their parent and inside the tree: the walk terminates
-            uint2 n;
-            if (curr < (uint32_t)kSTop)
-                n = slot[curr];
-            else
-                n = root[curr];
             const uint32_t left = n.y >> 16;
             if (left == 0u) {
                 v = __uint_as_float(n.x);
                 break;
             }
+            // the feature value and BOTH children (an aligned pair) are fetched together: one LDS round trip per level
             const float x = tile[(n.y & 0x7fffu) * kTileRows + lane];
-            curr = left + go_right(x, __uint_as_float(n.x), (n.y & 0x8000u) != 0u, missing);
+            uint4 pr;
+            if (left < (uint32_t)kSTop)
+                pr = *reinterpret_cast<const uint4 *>(slot + left);
+            else
+                pr = *reinterpret_cast<const uint4 *>(root + left);
+            const uint32_t r = go_right(x, __uint_as_float(n.x), (n.y & 0x8000u) != 0u, missing);
+            n = r ? make_uint2(pr.z, pr.w) : make_uint2(pr.x, pr.y);
+            curr = left + r;
         }
         if (WRITE_LEAF) {
             if (row_ok) leaf_out[row * (size_t)num_trees + t] = corig[ctrees[t] + curr];
@@ -254,6 +262,254 @@ __global__ void __launch_bounds__(NW * 64) sparse_top_kernel(const uint2 *__rest
         if (lane == 0) lds_flag_store(&ring_ready[e], (uint32_t)(t + 1));
     }
     if (dead && lane == 0) atomicOr(error_flag, 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The walk on rank-quantised features (strategy QRING on a sparse handle; num_cols <= 256).  The scheme of qring_kernel's
+// region form (qring.hip) with the tops of sparse_top_kernel: the quantise pass (quantize.hip) turns the batch into u16
+// codes, a tile is K regions of 64 rows x [fid][64] u16 (32 KiB each), so K = 3 chains per lane (192 rows) walk a tree
+// whose 512-node top is staged once -- three independent dependent-read chains per walker wave where the float32 tile
+// kernel has one, and 14 walkers.  Nodes are 8 bytes, {code << 16 | fid << 7 | def_left, left} or {leaf value, 0}; both
+// children (an aligned pair) come with one 16-byte read beside the code read, so a level is one LDS round trip.  Paths
+// differ in length: a chain that has reached its leaf keeps it (selects, no branches -- the reads of the K chains must
+// stay interleaved) until the longest path of the wave ends; children below the top are fetched from global memory for
+// the lanes that need them.  Leaf values go through the LDS ring to the consumer wave, which adds them in tree order:
+// the float32 sums are bit-identical to a sequential CPU sum.  Tree groups (a feature with more than 32767 distinct
+// thresholds) chain their sums like the dense form.
+template <int NWALK, bool WRITE_LEAF, int K, int RING>
+__global__ void __launch_bounds__((NWALK + 1) * 64)
+    sparse_q_kernel(const uint16_t *__restrict__ xq, const uint2 *__restrict__ qnodes, const int32_t *__restrict__ ctrees,
+                    const uint32_t *__restrict__ corig, float *__restrict__ sums, uint32_t *__restrict__ leaf_out, size_t rows,
+                    int cols, int tree_lo, int num_trees, int total_trees, const uint32_t *__restrict__ chunk_flags,
+                    int *__restrict__ error_flag, const float *sums_in, int cshift, size_t row_begin)
+{
+    // `rows` is the END of the rows this launch walks, row_begin (a multiple of 384) their start (see qreg_plan)
+    constexpr int TR = 64 * K;
+    constexpr int NT = (NWALK + 1) * 64;
+    constexpr int BATCH = RING >= 2 * kQBatch ? kQBatch : RING / 2;
+    static_assert(BATCH >= 1 && RING >= 2 * BATCH, "ring too small");
+    static_assert(kSTop * 8 == kQSlotBytes, "a top fills a walker slot");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned char *slots = smem + (size_t)K * kRegBytes;
+    float *ring_vals = reinterpret_cast<float *>(slots + (size_t)NWALK * kQSlotBytes);
+    uint32_t *ring_ready = reinterpret_cast<uint32_t *>(ring_vals + RING * TR);
+    uint32_t *consumed = ring_ready + RING;
+    const size_t row0 = row_begin + (size_t)blockIdx.x * TR;
+    if ((uint32_t)reinterpret_cast<uintptr_t>(smem) != 0u) {  // q_xread's v_bfi needs the regions at LDS address 0
+        if (tid == 0) atomicOr(error_flag, 2);
+        return;
+    }
+    {   // K consecutive regions of the workspace, each to its 32-KiB-aligned place
+        const int n16 = cols * kRegRows * 2 / 16;
+        for (int k = 0; k < K; ++k) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(xq + ((row0 >> 6) + (size_t)k) * ((size_t)cols * kRegRows));
+            uint4 *dst = reinterpret_cast<uint4 *>(smem + (size_t)k * kRegBytes);
+            for (int e = tid; e < n16; e += NT) dst[e] = src[e];
+        }
+    }
+    if (tid < RING) ring_ready[tid] = 0u;
+    if (tid == RING) *consumed = 0u;
+
+    if (wave == NWALK) {
+        // ================= consumer: ordered accumulation =================
+        __syncthreads();
+        float sum[K];  // continues the running sums of the previous tree group (sums_in may alias sums)
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const size_t irow = row0 + k * 64 + lane;
+            sum[k] = (sums_in && irow < rows) ? sums_in[irow] : 0.0f;
+        }
+        bool dead = false;
+        for (int t0 = 0; t0 < num_trees && !dead; t0 += BATCH) {
+            const int nb = min(BATCH, num_trees - t0);
+            int spins = 0;
+            for (;;) {
+                const bool ok = lane >= nb || lds_flag_load(&ring_ready[(t0 + lane) % RING]) == (uint32_t)(t0 + lane + 1);
+                if (__ballot(ok) == ~0ull) break;
+                if (++spins > kSSpinLimit) {
+                    dead = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (dead) break;
+            asm volatile("" ::: "memory");  // the values are read after the flags
+            for (int j = 0; j < nb; ++j) {
+                const int e = (t0 + j) % RING;
+#pragma unroll
+                for (int k = 0; k < K; ++k) sum[k] += ring_vals[e * TR + k * 64 + lane];  // tree order
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) lds_flag_store(consumed, (uint32_t)(t0 + nb));
+        }
+        if (dead && lane == 0) atomicOr(error_flag, 1);
+        if (sums) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const size_t orow = row0 + k * 64 + lane;
+                if (orow < rows) sums[orow] = sum[k];
+            }
+        }
+        return;
+    }
+
+    // ================= walkers =================
+    uint2 *slot = reinterpret_cast<uint2 *>(slots + (size_t)wave * kQSlotBytes);
+    uint4 pf0 = {}, pf1 = {}, pf2 = {}, pf3 = {};  // named registers (an indexed array would go to scratch)
+    auto prefetch_top = [&](int t) {  // clamped loads stay inside the tree's (16-byte padded) node range
+        const int32_t lo = ctrees[tree_lo + t], n = ctrees[tree_lo + t + 1] - lo;  // n is even
+        const uint4 *src = reinterpret_cast<const uint4 *>(qnodes + lo);
+        const int last = n / 2 - 1;
+        pf0 = src[min(0 * 64 + lane, last)];
+        pf1 = src[min(1 * 64 + lane, last)];
+        pf2 = src[min(2 * 64 + lane, last)];
+        pf3 = src[min(3 * 64 + lane, last)];
+    };
+    auto commit_top = [&]() {
+        uint4 *s = reinterpret_cast<uint4 *>(slot);
+        s[0 * 64 + lane] = pf0;
+        s[1 * 64 + lane] = pf1;
+        s[2 * 64 + lane] = pf2;
+        s[3 * 64 + lane] = pf3;
+    };
+    if (wave < num_trees) {
+        prefetch_top(wave);
+        commit_top();
+    }
+    __syncthreads();  // the regions, the ring state and (own wave) the first top are in LDS
+
+    bool dead = false;
+    auto run = [&](auto ms_tag) {
+        constexpr bool MS = decltype(ms_tag)::value;
+        uint32_t pos[K];  // LDS byte address of this lane's row in feature column 0 of region k
+#pragma unroll
+        for (int k = 0; k < K; ++k) pos[k] = (uint32_t)(k * kRegBytes) + 2u * (uint32_t)qreg_pos(lane);
+        for (int t = wave; t < num_trees && !dead; t += NWALK) {
+            const bool more = t + NWALK < num_trees;
+            if (more) prefetch_top(t + NWALK);
+            const uint2 *root = qnodes + ctrees[tree_lo + t];
+            uint2 n[K];
+            uint32_t curr[K];
+            {
+                const uint2 r1 = slot[1];  // the root; position 0 is padding
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    n[k] = r1;
+                    curr[k] = 1u;
+                }
+            }
+            for (;;) {  // create() guarantees children after their parent and inside the tree: the walks terminate
+                uint32_t open = n[0].y;
+#pragma unroll
+                for (int k = 1; k < K; ++k) open |= n[k].y;
+                if (__ballot(open != 0u) == 0ull) break;  // every chain of the wave holds its leaf
+                uint32_t xc[K];
+                uint4 pr[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) {  // a finished chain reads some code and the padding pair: harmless
+                    xc[k] = q_xread<true, true, 7>(nullptr, n[k].x, pos[k]);
+                    pr[k] = *reinterpret_cast<const uint4 *>(&slot[min(n[k].y, (uint32_t)(kSTop - 2))]);
+                }
+#pragma unroll
+                for (int k = 0; k < K; ++k)  // children below the top: from global memory, for the lanes that are there
+                    if (__ballot(n[k].y >= (uint32_t)kSTop) != 0ull) {
+                        if (n[k].y >= (uint32_t)kSTop) pr[k] = *reinterpret_cast<const uint4 *>(root + n[k].y);
+                    }
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const bool r = q_go_right<MS, true>(xc[k], n[k].x);
+                    const bool live = n[k].y != 0u;
+                    const uint32_t cx = r ? pr[k].z : pr[k].x, cy = r ? pr[k].w : pr[k].y;
+                    if (WRITE_LEAF) curr[k] = live ? n[k].y + (r ? 1u : 0u) : curr[k];
+                    n[k].x = live ? cx : n[k].x;
+                    n[k].y = live ? cy : 0u;
+                }
+            }
+            if (WRITE_LEAF) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const size_t row = row0 + k * 64 + lane;
+                    if (row < rows) leaf_out[row * (size_t)total_trees + tree_lo + t] = corig[ctrees[tree_lo + t] + curr[k]];
+                }
+            }
+            if (t >= RING) {  // ring entry still in use by tree t - RING?
+                int spins = 0;
+                while (lds_flag_load(consumed) < (uint32_t)(t - RING + 1)) {
+                    if (++spins > kSSpinLimit) {
+                        dead = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+            const int e = t % RING;
+#pragma unroll
+            for (int k = 0; k < K; ++k) ring_vals[e * TR + k * 64 + lane] = __uint_as_float(n[k].x);
+            asm volatile("" ::: "memory");  // values before the flag: a wave's LDS operations are performed in issue order
+            if (lane == 0) lds_flag_store(&ring_ready[e], (uint32_t)(t + 1));
+            if (more) commit_top();  // this wave's reads of its slot are done (in-order LDS)
+        }
+    };
+    // chunk_flags[c] != 0 <=> the quantise pass met a missing value in rows [c, c+1) << cshift; a tile can straddle two chunks
+    if ((chunk_flags[row0 >> cshift] | chunk_flags[(min(rows, row0 + TR) - 1) >> cshift]) != 0)
+        run(std::true_type{});
+    else
+        run(std::false_type{});
+    if (dead && lane == 0) atomicOr(error_flag, 1);
+}
+
+bool sparse_q_available(const tahoe_forest *f) { return f->sp && f->sp->qnodes && f->q; }
+
+template <int NWALK, int K, int RING>
+static void sparse_q_launch_form(tahoe_forest *f, const tahoe_qgroup &g, float *sums, const float *sums_in, uint32_t *leaf_out,
+                                 size_t row_begin, size_t rows_end, hipStream_t stream, int cshift)
+{
+    const tahoe_sstate *sp = f->sp;
+    const unsigned grid = (unsigned)((rows_end - row_begin + 64 * K - 1) / (64 * K));
+    if (grid == 0) return;
+    const int lds = (int)qreg_lds_for(K, NWALK, RING);
+    if (leaf_out)
+        hipLaunchKernelGGL((sparse_q_kernel<NWALK, true, K, RING>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, f->q->xq, sp->qnodes,
+                           sp->ctrees, sp->corig, sums, leaf_out, rows_end, f->p.num_cols, g.tree_lo, g.num_trees, f->p.num_trees,
+                           f->q->chunk_flags, f->error_flag, sums_in, cshift, row_begin);
+    else
+        hipLaunchKernelGGL((sparse_q_kernel<NWALK, false, K, RING>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, f->q->xq, sp->qnodes,
+                           sp->ctrees, sp->corig, sums, leaf_out, rows_end, f->p.num_cols, g.tree_lo, g.num_trees, f->p.num_trees,
+                           f->q->chunk_flags, f->error_flag, sums_in, cshift, row_begin);
+}
+
+// quantise + walk per tree group, in stream order; the tile plan of the dense region form (qreg_plan)
+static tahoe_status sparse_q_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, const float *data, size_t rows,
+                                    hipStream_t stream, const float *sums_in0)
+{
+    if (!sparse_q_available(f))
+        return fail(TAHOE_ERR_UNSUPPORTED, "sparse QRING needs num_cols <= 256, trees of <= 65535 nodes and <= %d distinct thresholds "
+                                           "per feature within one tree", kQMaxTable);
+    tahoe_qstate *q = f->q;
+    const tahoe_status rs = qring_reserve(f, rows);  // no-op unless this batch is larger than any before
+    if (rs != TAHOE_OK) return rs;
+    size_t rows3 = 0;
+    int chains = 2;
+    qreg_plan(rows, f->num_cus, f->knob_qring_chains, &rows3, &chains);
+    bool first = true;
+    for (const tahoe_qgroup &g : q->groups) {
+        TAHOE_HIP_TRY(hipMemsetAsync(q->chunk_flags, 0, q->n_chunk_flags * sizeof(uint32_t), stream));
+        int cshift = 0;
+        const tahoe_status qs = quantize_launch(f, g, data, rows, 6, 1, stream, &cshift);
+        if (qs != TAHOE_OK) return qs;
+        const float *sums_in = first ? sums_in0 : sums;  // later groups continue the running float32 sums
+        if (rows3 > 0) sparse_q_launch_form<kReg3Walkers, 3, kReg3Ring>(f, g, sums, sums_in, leaf_out, 0, rows3, stream, cshift);
+        if (chains == 3)
+            sparse_q_launch_form<kReg3Walkers, 3, kReg3Ring>(f, g, sums, sums_in, leaf_out, rows3, rows, stream, cshift);
+        else
+            sparse_q_launch_form<15, 2, kQRing>(f, g, sums, sums_in, leaf_out, rows3, rows, stream, cshift);
+        TAHOE_HIP_TRY(hipGetLastError());
+        first = false;
+    }
+    return TAHOE_OK;
 }
 
 static long long sparse_top_lds(const tahoe_forest *f, int nw)
@@ -284,6 +540,7 @@ tahoe_status sparse_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, con
     const tahoe_sstate *sp = f->sp;
     const unsigned grid = (unsigned)((rows + kTileRows - 1) / kTileRows);
     const int vec4_ok = (f->p.num_cols % 4 == 0) && ((reinterpret_cast<uintptr_t>(data) & 15u) == 0);
+    if (strategy == TAHOE_STRATEGY_QRING) return sparse_q_launch(f, sums, leaf_out, data, rows, stream, sums_in);
     if (strategy == TAHOE_STRATEGY_TILEBLOCK) {
         const int nw = sparse_top_waves(f);
         if (nw == 0) return fail(TAHOE_ERR_UNSUPPORTED, "sparse TILEBLOCK: the compact form or its LDS tile is unavailable");
@@ -335,8 +592,117 @@ void sparse_destroy(tahoe_forest *f)
     if (f->sp->cnodes) (void)hipFree(f->sp->cnodes);
     if (f->sp->ctrees) (void)hipFree(f->sp->ctrees);
     if (f->sp->corig) (void)hipFree(f->sp->corig);
+    if (f->sp->qnodes) (void)hipFree(f->sp->qnodes);
     delete f->sp;
     f->sp = nullptr;
+}
+
+// Quantised copy of the compact form (sparse_q_kernel) + the quantiser's tables, per tree group.  `cn` / `ct` = the compact
+// nodes and tree offsets just built.  Leaves the strategy unavailable (TAHOE_OK, sp->qnodes null) when num_cols > 256, the
+// region tile does not fit LDS, or a single tree uses more than kQMaxTable distinct thresholds on one feature.
+static tahoe_status sparse_q_build(tahoe_forest *f, const std::vector<uint2> &cn, const std::vector<int32_t> &ct)
+{
+    tahoe_sstate *sp = f->sp;
+    const int cols = f->p.num_cols;
+    const size_t T = (size_t)f->p.num_trees;
+    if (const char *e = getenv("TAHOE_SPARSE_QRING"))  // experiments: 0 keeps the float32 kernels only
+        if (atoi(e) == 0) return TAHOE_OK;
+    if (cols < 1 || cols > 256 || T == 0 || qreg_lds_for(3, kReg3Walkers, kReg3Ring) > f->lds_limit ||
+        qreg_lds_for(2, 15, kQRing) > f->lds_limit)
+        return TAHOE_OK;
+    tahoe_qstate *q = new (std::nothrow) tahoe_qstate();
+    if (!q) return fail(TAHOE_ERR_NO_MEMORY, "sparse_q_build");
+    f->q = q;
+    q->narrow = q->reg = q->sparse = true;  // region workspace (qring_reserve), region node words
+    if (const char *k = getenv("TAHOE_QRING_CHAINS")) f->knob_qring_chains = atoi(k);  // 2 / 3: force the tile form
+    auto is_inner = [](const uint2 &c) { return (c.y >> 16) != 0u; };
+    auto thr_of = [](const uint2 &c) {
+        float v;
+        memcpy(&v, &c.x, 4);
+        return v;
+    };
+    // tree groups: G as small as the busiest feature allows (first guess from node counts, then grow until every group fits)
+    size_t G = 1;
+    {
+        std::vector<size_t> per_feature((size_t)cols, 0);
+        for (const uint2 &c : cn)
+            if (is_inner(c) && !std::isnan(thr_of(c))) ++per_feature[c.y & 0x7fffu];
+        const size_t most = *std::max_element(per_feature.begin(), per_feature.end());
+        if (most > (size_t)kQMaxTable + kQMaxTable / 2) G = (most + kQMaxTable - 1) / kQMaxTable;
+    }
+    std::vector<uint2> qn(cn.size());
+    const size_t bytes_before = f->device_bytes;
+    auto drop_groups = [&]() {
+        for (tahoe_qgroup &g : q->groups) quantize_free_tables(g);
+        q->groups.clear();
+        f->device_bytes = bytes_before;
+    };
+    for (;;) {
+        if (G > T) G = T;
+        bool fits = true;
+        int worst = 0;
+        for (size_t k = 0; k < G && fits; ++k) {
+            const size_t lo = T * k / G, hi = T * (k + 1) / G;
+            const size_t n_lo = (size_t)ct[lo], n_hi = (size_t)ct[hi];
+            std::vector<std::vector<float>> tab((size_t)cols);
+            for (size_t i = n_lo; i < n_hi; ++i)
+                if (is_inner(cn[i]) && !std::isnan(thr_of(cn[i]))) tab[cn[i].y & 0x7fffu].push_back(thr_of(cn[i]));
+            parallel_for((size_t)cols, 4, [&tab](size_t c_lo, size_t c_hi) {
+                for (size_t c = c_lo; c < c_hi; ++c) {
+                    auto &v = tab[c];
+                    std::sort(v.begin(), v.end());                      // float order; -0.0f and 0.0f compare equal
+                    v.erase(std::unique(v.begin(), v.end()), v.end());  // ... and collapse into one entry
+                }
+            });
+            int max_count = 0;
+            for (int c = 0; c < cols; ++c) max_count = std::max(max_count, (int)tab[c].size());
+            if (max_count > kQMaxTable) {
+                fits = false;
+                worst = max_count;
+                break;
+            }
+            parallel_for(n_hi - n_lo, 1 << 16, [&](size_t a, size_t b) {
+                for (size_t i = n_lo + a; i < n_lo + b; ++i) {
+                    const uint2 c = cn[i];
+                    if (!is_inner(c)) {
+                        qn[i] = make_uint2(c.x, 0u);  // leaf (and padding): the value, no children
+                        continue;
+                    }
+                    const uint32_t fid = c.y & 0x7fffu, dl = (c.y >> 15) & 1u;
+                    const float thr = thr_of(c);
+                    uint32_t code = 0xFFFFu;  // x >= NaN is never true; a missing x still follows def_left
+                    if (!std::isnan(thr)) {
+                        const auto &v = tab[fid];
+                        code = (uint32_t)(std::lower_bound(v.begin(), v.end(), thr) - v.begin()) + 1u;
+                    }
+                    qn[i] = make_uint2((code << 16) | (fid << 7) | dl, c.y >> 16);
+                }
+            });
+            tahoe_qgroup g;
+            g.tree_lo = (int)lo;
+            g.num_trees = (int)(hi - lo);
+            const tahoe_status bs = quantize_build_tables(f, tab, g);
+            q->groups.push_back(g);  // owned by the handle from here (freed by qring_destroy)
+            if (bs != TAHOE_OK) return bs;
+        }
+        if (fits) break;
+        drop_groups();
+        if (G == T) {  // a single tree exceeds the code range: the strategy is unavailable
+            qring_destroy(f);
+            return TAHOE_OK;
+        }
+        G = std::max(G + 1, (size_t)((double)G * worst / kQMaxTable + 0.999));
+    }
+    hipError_t e;
+    if ((e = q_upload(&sp->qnodes, qn.data(), qn.size(), &f->device_bytes)) != hipSuccess)
+        return fail(TAHOE_ERR_HIP, "sparse_q_build: qnodes failed: %s", hipGetErrorString(e));
+    for (const void *k : {(const void *)&sparse_q_kernel<kReg3Walkers, false, 3, kReg3Ring>, (const void *)&sparse_q_kernel<kReg3Walkers, true, 3, kReg3Ring>,
+                          (const void *)&sparse_q_kernel<15, false, 2, kQRing>, (const void *)&sparse_q_kernel<15, true, 2, kQRing>})
+        if ((e = allow_max_lds(k, f->lds_limit)) != hipSuccess)
+            return fail(TAHOE_ERR_HIP, "sparse_q_build: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    if ((e = quantize_allow_lds(f)) != hipSuccess)
+        return fail(TAHOE_ERR_HIP, "sparse_q_build: hipFuncSetAttribute(quantise kernels) failed: %s", hipGetErrorString(e));
+    return TAHOE_OK;
 }
 
 }  // namespace tahoe
@@ -435,26 +801,30 @@ tahoe_status tahoe_sparse_forest_create(tahoe_forest **out, const int32_t *trees
             const tahoe_sparse_node *tn = nodes + lo;
             // breadth-first order of the reachable nodes; a child pair stays adjacent
             order.assign(1, 0u);
-            for (size_t q = 0; q < order.size() && order.size() <= 65536; ++q) {
+            for (size_t q = 0; q < order.size() && order.size() <= 65535; ++q) {
                 const tahoe_sparse_node &n = tn[order[q]];
                 if (n.bits & kSIsLeaf) continue;
                 order.push_back((uint32_t)n.left_idx);
                 order.push_back((uint32_t)n.left_idx + 1u);
             }
-            if (order.size() > 65536) {
+            if (order.size() > 65535) {
                 ok = false;
                 break;
             }
+            // position 0 of a tree is padding and the root sits at 1, so that every child pair (appended two at a time)
+            // starts at an even position: one aligned 16-byte read fetches both children
             newpos.assign((size_t)(hi - lo), 0u);
-            for (size_t q = 0; q < order.size(); ++q) newpos[order[q]] = (uint32_t)q;
+            for (size_t q = 0; q < order.size(); ++q) newpos[order[q]] = (uint32_t)q + 1u;
             ct[(size_t)t] = (int32_t)cn.size();
+            cn.push_back(make_uint2(0u, 0u));
+            orig.push_back(0u);
             for (size_t q = 0; q < order.size(); ++q) {
                 const tahoe_sparse_node &n = tn[order[q]];
                 uint2 c;
                 memcpy(&c.x, &n.val, 4);
                 if (n.bits & kSIsLeaf)
                     c.y = 0u;
-                else  // the left child of any node sits at a position >= 1: 0 marks a leaf
+                else  // the left child of any node sits at a position >= 2: 0 marks a leaf
                     c.y = (newpos[(size_t)n.left_idx] << 16) | ((n.bits & kSDefLeft) ? 0x8000u : 0u) | (uint32_t)(n.bits & kSFidMask);
                 cn.push_back(c);
                 orig.push_back(order[q]);
@@ -477,6 +847,11 @@ tahoe_status tahoe_sparse_forest_create(tahoe_forest **out, const int32_t *trees
             for (const void *k : {(const void *)&sparse_top_kernel<16, false>, (const void *)&sparse_top_kernel<16, true>,
                                   (const void *)&sparse_top_kernel<8, false>, (const void *)&sparse_top_kernel<8, true>})
                 if ((e = allow_max_lds(k, f->lds_limit)) != hipSuccess) return bail(e, "hipFuncSetAttribute(sparse_top)");
+            const tahoe_status qs = sparse_q_build(f, cn, ct);
+            if (qs != TAHOE_OK) {
+                tahoe_forest_destroy(f);
+                return qs;
+            }
         }
     }
     *out = f;

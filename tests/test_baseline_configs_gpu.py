@@ -173,7 +173,8 @@ def test_k5_irregular_sparse_forest(env):
     assert np.array_equal(bits(got[idx]), bits(want))
     leaf, _ = forest.predict_leaf_idx(x[torch.from_numpy(idx).cuda()].contiguous(), want_sums=False)
     assert np.array_equal(bits(leaf.cpu().numpy()), want_leaf)
-    for s in (ta.STRATEGY_DIRECT, ta.STRATEGY_ROWTILE):  # the two other sparse kernels, every row
+    assert forest.get_strategy(R) == ta.STRATEGY_QRING  # the walk on quantised codes
+    for s in (ta.STRATEGY_DIRECT, ta.STRATEGY_ROWTILE, ta.STRATEGY_TILEBLOCK):  # the float32 sparse kernels, every row
         forest.set_strategy(s)
         assert np.array_equal(bits(forest.predict_raw(x).cpu().numpy()), bits(got)), s
     forest.set_strategy(ta.STRATEGY_AUTO)

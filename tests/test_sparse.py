@@ -88,8 +88,14 @@ def test_sparse_walk_on_gpu(ta):
                 assert err.status == 7 and cols > 512  # unavailable only when the tile does not fit
         if cols <= 512:
             assert ta.STRATEGY_TILEBLOCK in strategies
-            f.set_strategy(ta.STRATEGY_AUTO)
-            assert f.get_strategy(len(data_)) == ta.STRATEGY_TILEBLOCK
+            f.set_strategy(ta.STRATEGY_QRING)  # the walk on quantised codes: num_cols <= 256
+            strategies.append(ta.STRATEGY_QRING)
+            f.set_strategy(ta.STRATEGY_AUTO)  # QRING when there is enough walking per feature value to pay the quantise pass
+            n_trees = len(tr_)
+            assert f.get_strategy(len(data_)) == (ta.STRATEGY_QRING if 20 * n_trees >= 13 * cols else ta.STRATEGY_TILEBLOCK)
+        else:
+            with pytest.raises(ta.TahoeError):
+                f.set_strategy(ta.STRATEGY_QRING)
         for strategy in strategies:
             f.set_strategy(strategy)
             leaf, sums = f.predict_leaf_idx(x)
@@ -98,8 +104,6 @@ def test_sparse_walk_on_gpu(ta):
             assert np.array_equal(leaf.cpu().numpy().view(np.uint32), want_leaf)
             assert np.array_equal(sums.cpu().numpy().view(np.uint32), want.view(np.uint32))
             assert np.array_equal(raw.cpu().numpy().view(np.uint32), want.view(np.uint32))
-        with pytest.raises(ta.TahoeError):
-            f.set_strategy(ta.STRATEGY_QRING)
     # hand-made: a root that is a leaf, a 3-node tree, an orphan pair nobody links to, fewer trees than waves
     nd = np.zeros(8, dtype=sn.dtype)
     LEAF = np.int32(-2**31)
@@ -111,7 +115,7 @@ def test_sparse_walk_on_gpu(ta):
     want, want_leaf = oracle.sparse_predict(nd, roots, xs, MISSING, want_leaf=True)
     assert want.tolist() == [9.0, 12.0, 9.0, 12.0]  # 7 + (x1 >= 0.5 or missing&!def_left ? 2 : -1) + 3
     f = ta.capi.SparseForest(nd, roots, 2, missing=MISSING)
-    for strategy in (ta.STRATEGY_TILEBLOCK, ta.STRATEGY_ROWTILE, ta.STRATEGY_DIRECT):
+    for strategy in (ta.STRATEGY_QRING, ta.STRATEGY_TILEBLOCK, ta.STRATEGY_ROWTILE, ta.STRATEGY_DIRECT):
         f.set_strategy(strategy)
         leaf, sums = f.predict_leaf_idx(torch.from_numpy(xs).cuda())
         assert np.array_equal(sums.cpu().numpy().view(np.uint32), want.view(np.uint32))
@@ -123,8 +127,9 @@ def test_sparse_walk_on_gpu(ta):
     want, want_leaf = oracle.sparse_predict(big, big_tr, bx, MISSING, want_leaf=True, threads=8)
     f = ta.capi.SparseForest(big, big_tr, 8, missing=MISSING)
     assert f.get_strategy(500) == ta.STRATEGY_ROWTILE
-    with pytest.raises(ta.TahoeError):
-        f.set_strategy(ta.STRATEGY_TILEBLOCK)
+    for unavailable in (ta.STRATEGY_TILEBLOCK, ta.STRATEGY_QRING):
+        with pytest.raises(ta.TahoeError):
+            f.set_strategy(unavailable)
     leaf, sums = f.predict_leaf_idx(torch.from_numpy(bx).cuda())
     assert np.array_equal(sums.cpu().numpy().view(np.uint32), want.view(np.uint32))
     assert np.array_equal(leaf.cpu().numpy().view(np.uint32), want_leaf)
@@ -135,3 +140,63 @@ def test_sparse_walk_on_gpu(ta):
     with pytest.raises(ta.TahoeError) as e:
         ta.capi.SparseForest(bad, tr, C)
     assert e.value.status == 6
+
+
+@pytest.mark.gpu
+def test_sparse_quantised_walk_tree_groups_and_tile_plans(ta):
+    """QRING on a sparse handle: a feature with more than 32767 distinct thresholds cuts the forest into tree groups whose
+    float32 sums are chained; batches that end in a partly filled tile, 192- and 128-row tile forms, missing / NaN / inf
+    inputs, continued sums, and a batch after a larger one (workspace re-use)."""
+    import torch
+
+    cols = 2
+    sn, tr = ta.capi.synth_sparse_forest(48, cols, 10, 14, 0.05, 65535, 91)
+    inner = (sn["bits"].view(np.uint32) >> 31) == 0
+    per_feature = np.bincount(sn["bits"][inner] & ((1 << 30) - 1), minlength=cols)
+    assert per_feature.max() > 40_000  # more than one group's worth of thresholds on a feature
+    rows = 5000
+    data = ta.synth_data(rows, cols, seed=92, missing_prob=0.1, missing=MISSING, nan_prob=0.05)
+    data[7, 0], data[8, 1], data[9, 0] = np.inf, -np.inf, -0.0
+    want, want_leaf = oracle.sparse_predict(sn, tr, data, MISSING, want_leaf=True, threads=8)
+    f = ta.capi.SparseForest(sn, tr, cols, missing=MISSING)
+    f.set_strategy(ta.STRATEGY_QRING)
+    x = torch.from_numpy(data).cuda()
+    for n in (rows, 1, 63, 64, 65, 127, 129, 191, 193, 385, 4097):
+        leaf, sums = f.predict_leaf_idx(x[:n].contiguous())
+        raw = f.predict_raw(x[:n].contiguous())
+        f.check()
+        assert np.array_equal(leaf.cpu().numpy().view(np.uint32), want_leaf[:n]), n
+        assert np.array_equal(sums.cpu().numpy().view(np.uint32), want[:n].view(np.uint32)), n
+        assert np.array_equal(raw.cpu().numpy().view(np.uint32), want[:n].view(np.uint32)), n
+    # continued sums: the forest cut in two handles, the second continues the first one's float32 sums
+    cut = 24
+    fa = ta.capi.SparseForest(sn[: tr[cut]], tr[:cut], cols, missing=MISSING)
+    fb = ta.capi.SparseForest(sn[tr[cut]:], tr[cut:] - tr[cut], cols, missing=MISSING)
+    for h in (fa, fb):
+        h.set_strategy(ta.STRATEGY_QRING)
+    acc = fa.predict_raw(x)
+    fb.predict_accumulate(x, acc)
+    fa.check()
+    fb.check()
+    assert np.array_equal(acc.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    # a wider forest, without missing values (the single-compare fast path), both tile forms forced
+    import os
+    sn2, tr2 = ta.capi.synth_sparse_forest(300, 256, 4, 24, 0.32, 65535, 93)
+    d2 = ta.synth_data(3000, 256, seed=94)
+    want2, leaf2 = oracle.sparse_predict(sn2, tr2, d2, MISSING, want_leaf=True, threads=8)
+    x2 = torch.from_numpy(d2).cuda()
+    for chains in ("2", "3", None):
+        if chains is None:
+            os.environ.pop("TAHOE_QRING_CHAINS", None)
+        else:
+            os.environ["TAHOE_QRING_CHAINS"] = chains
+        try:
+            f2 = ta.capi.SparseForest(sn2, tr2, 256, missing=MISSING)
+        finally:
+            os.environ.pop("TAHOE_QRING_CHAINS", None)
+        assert f2.get_strategy(3000) == ta.STRATEGY_QRING
+        leaf, sums = f2.predict_leaf_idx(x2)
+        f2.check()
+        assert np.array_equal(leaf.cpu().numpy().view(np.uint32), leaf2), chains
+        assert np.array_equal(sums.cpu().numpy().view(np.uint32), want2.view(np.uint32)), chains
+        f2.close()
