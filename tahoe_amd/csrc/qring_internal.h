@@ -88,8 +88,9 @@ inline long long qreg_lds_for(int k, int nwalk, int ring)
 // walked as n whole waves of 192-row tiles followed by a remainder in whichever form is cheaper, n chosen to minimise
 // 1.33 n + remainder (125 k rows: 2 waves of 192-row tiles + 209 tiles of 128 = 3.8 instead of 4 waves of 128-row tiles;
 // 10 k rows: 79 tiles of 128).  Any cut is correct.  *rows3 = rows [0, rows3) in 192-row tiles (a multiple of 384),
-// *chains = form of the remaining rows [rows3, rows).  `force` = 2 / 3: one form for the whole batch.
-inline void qreg_plan(size_t rows, int num_cus, int force, size_t *rows3, int *chains)
+// *chains = form of the remaining rows [rows3, rows).  `force` = 2 / 3: one form for the whole batch.  cost3 = time of a
+// 192-row tile in percent of a 128-row tile (dense walk: 133; the sparse walk's three chains cost more: 161, sparse.hip).
+inline void qreg_plan(size_t rows, int num_cus, int force, size_t *rows3, int *chains, size_t cost3 = 133)
 {
     *rows3 = 0;
     *chains = 2;
@@ -102,8 +103,8 @@ inline void qreg_plan(size_t rows, int num_cus, int force, size_t *rows3, int *c
     size_t best = SIZE_MAX;
     for (size_t n = 0; n <= waves(rows, 192); ++n) {
         const size_t r3 = std::min(rows, n * cus * 192 / 384 * 384), rem = rows - r3;
-        const size_t c2 = 100 * waves(rem, 128), c3 = 133 * waves(rem, 192);
-        const size_t cost = 133 * waves(r3, 192) + std::min(c2, c3);
+        const size_t c2 = 100 * waves(rem, 128), c3 = cost3 * waves(rem, 192);
+        const size_t cost = cost3 * waves(r3, 192) + std::min(c2, c3);
         if (cost < best) {
             best = cost;
             *rows3 = rem ? r3 : 0;               // a pure 192-row plan is "no first part, remainder in form 3"

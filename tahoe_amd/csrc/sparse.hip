@@ -32,10 +32,22 @@ struct tahoe_sstate {
     uint2 *cnodes = nullptr;    // x = value bits; y = left_idx << 16 | def_left << 15 | fid, left_idx == 0 <=> leaf; root at 1, pairs even
     int32_t *ctrees = nullptr;  // [T + 1] offsets into cnodes (even)
     uint32_t *corig = nullptr;  // compact position -> index relative to the root in the caller's numbering
-    // quantised copy of the compact form for sparse_q_kernel (null when num_cols > 256 or a single tree exceeds the code
-    // range): same positions as cnodes; inner node x = code << 16 | fid << 7 | def_left, y = left position; leaf x = value
-    // bits, y = 0.  The threshold tables, the code workspace and the tree groups live in f->q (qring_internal.h).
-    uint2 *qnodes = nullptr;
+    // quantised form for sparse_q_kernel (null when num_cols > 256 or a single tree exceeds the code range); the threshold
+    // tables, the code workspace and the tree groups live in f->q (qring_internal.h).  Node word = code << 16 | fid << 7 |
+    // def_left (bits 6..1 free for flags).
+    // qtop [T][1024] u32: the first kSQLevels levels of every tree as a complete heap (early leaves padded down), the form the
+    //   walker slots hold: entries 1..511 node words (1-based heap positions, children of i = 2i, 2i+1; bits 1 / 2 of a
+    //   last-level word: the left / right child continues below the top), entries 512..1023 what lies below each last-level
+    //   branch: a leaf value, or the index (within the tree) of the block where the walk goes on
+    // qblocks: 32-byte blocks {n0, n1, n2, flags} {e0..e3}: a node, its two children, and what lies below each of the four
+    //   branches: a leaf value or (flags bit j) the index of the next block; a child that is a leaf is a padding word with its
+    //   value below both branches.  qblkoff [T + 1]: first block of each tree.
+    // qbotpos [T][512], qblkpos [blocks][4]: compact position (corig index) of every entry, for the leaf-index output
+    uint32_t *qtop = nullptr;
+    uint4 *qblocks = nullptr;
+    int32_t *qblkoff = nullptr;
+    uint32_t *qbotpos = nullptr;
+    uint32_t *qblkpos = nullptr;
 };
 
 namespace tahoe {
@@ -266,29 +278,38 @@ __global__ void __launch_bounds__(NW * 64) sparse_top_kernel(const uint2 *__rest
 
 // ------------------------------------------------------------------------------------------------
 // The walk on rank-quantised features (strategy QRING on a sparse handle; num_cols <= 256).  The scheme of qring_kernel's
-// region form (qring.hip) with the tops of sparse_top_kernel: the quantise pass (quantize.hip) turns the batch into u16
-// codes, a tile is K regions of 64 rows x [fid][64] u16 (32 KiB each), so K = 3 chains per lane (192 rows) walk a tree
-// whose 512-node top is staged once -- three independent dependent-read chains per walker wave where the float32 tile
-// kernel has one, and 14 walkers.  Nodes are 8 bytes, {code << 16 | fid << 7 | def_left, left} or {leaf value, 0}; both
-// children (an aligned pair) come with one 16-byte read beside the code read, so a level is one LDS round trip.  Paths
-// differ in length: a chain that has reached its leaf keeps it (selects, no branches -- the reads of the K chains must
-// stay interleaved) until the longest path of the wave ends; children below the top are fetched from global memory for
-// the lanes that need them.  Leaf values go through the LDS ring to the consumer wave, which adds them in tree order:
-// the float32 sums are bit-identical to a sequential CPU sum.  Tree groups (a feature with more than 32767 distinct
-// thresholds) chain their sums like the dense form.
+// region form (qring.hip): the quantise pass (quantize.hip) turns the batch into u16 codes, a tile is K regions of 64 rows x
+// [fid][64] u16 (32 KiB each), K = 3 chains per lane (192 rows) walk a tree whose top is staged once into the walker's
+// 4 KiB LDS slot -- three independent dependent-read chains per walker wave where the float32 tile kernel has one.
+// Top of a tree = its first kSQLevels = 9 levels as a COMPLETE heap (an early leaf is padded down to the last level: both
+// children of a padding node carry the value), 4-byte node words code << 16 | fid << 7 | def_left at 1-based positions, so
+// the children of i are the aligned pair (2i, 2i+1): one ds_read_b64 beside the code read, one v_addc per level, no
+// per-lane "am I at a leaf yet" state -- the irregular shape costs nothing inside the top.  Entries 512..1023 hold what
+// lies below each last-level branch: a leaf value (most lanes end here) or, flagged in the last-level node word, the
+// index of a 32-byte BLOCK in global memory: a node, its two children and what lies below their four branches (a value, or
+// the next block).  One gather of a block advances a walk by two levels; only the lanes whose path goes on take part (K5:
+// 14 of 192 on average, but 4 more levels for the longest), and the first block of tree t is gathered before the top of
+// tree t + NWALK is walked and used after it -- a software pipeline, as the dense form does with its bottom blocks.
+// Leaf values go through the LDS ring to the consumer wave, which adds them in tree order: the float32 sums are
+// bit-identical to a sequential CPU sum.  Tree groups (a feature with more than 32767 distinct thresholds) chain their
+// sums like the dense form.
+constexpr int kSQLevels = 9;
 template <int NWALK, bool WRITE_LEAF, int K, int RING>
 __global__ void __launch_bounds__((NWALK + 1) * 64)
-    sparse_q_kernel(const uint16_t *__restrict__ xq, const uint2 *__restrict__ qnodes, const int32_t *__restrict__ ctrees,
-                    const uint32_t *__restrict__ corig, float *__restrict__ sums, uint32_t *__restrict__ leaf_out, size_t rows,
-                    int cols, int tree_lo, int num_trees, int total_trees, const uint32_t *__restrict__ chunk_flags,
-                    int *__restrict__ error_flag, const float *sums_in, int cshift, size_t row_begin)
+    sparse_q_kernel(const uint16_t *__restrict__ xq, const uint32_t *__restrict__ qtop, const uint4 *__restrict__ qblocks,
+                    const int32_t *__restrict__ qblkoff, const uint32_t *__restrict__ qbotpos, const uint32_t *__restrict__ qblkpos,
+                    const int32_t *__restrict__ ctrees, const uint32_t *__restrict__ corig,
+                    float *__restrict__ sums, uint32_t *__restrict__ leaf_out, size_t rows, int cols, int tree_lo, int num_trees,
+                    int total_trees, const uint32_t *__restrict__ chunk_flags, int *__restrict__ error_flag, const float *sums_in,
+                    int cshift, size_t row_begin)
 {
     // `rows` is the END of the rows this launch walks, row_begin (a multiple of 384) their start (see qreg_plan)
     constexpr int TR = 64 * K;
     constexpr int NT = (NWALK + 1) * 64;
     constexpr int BATCH = RING >= 2 * kQBatch ? kQBatch : RING / 2;
+    constexpr uint32_t NBOT = 1u << kSQLevels;  // entries below the top; the slot holds 2 * NBOT words
     static_assert(BATCH >= 1 && RING >= 2 * BATCH, "ring too small");
-    static_assert(kSTop * 8 == kQSlotBytes, "a top fills a walker slot");
+    static_assert(2 * NBOT * 4 == kQSlotBytes, "a top fills a walker slot");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -357,16 +378,14 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
     }
 
     // ================= walkers =================
-    uint2 *slot = reinterpret_cast<uint2 *>(slots + (size_t)wave * kQSlotBytes);
+    uint32_t *slot = reinterpret_cast<uint32_t *>(slots + (size_t)wave * kQSlotBytes);
     uint4 pf0 = {}, pf1 = {}, pf2 = {}, pf3 = {};  // named registers (an indexed array would go to scratch)
-    auto prefetch_top = [&](int t) {  // clamped loads stay inside the tree's (16-byte padded) node range
-        const int32_t lo = ctrees[tree_lo + t], n = ctrees[tree_lo + t + 1] - lo;  // n is even
-        const uint4 *src = reinterpret_cast<const uint4 *>(qnodes + lo);
-        const int last = n / 2 - 1;
-        pf0 = src[min(0 * 64 + lane, last)];
-        pf1 = src[min(1 * 64 + lane, last)];
-        pf2 = src[min(2 * 64 + lane, last)];
-        pf3 = src[min(3 * 64 + lane, last)];
+    auto prefetch_top = [&](int t) {  // 4 KiB per tree, 16 bytes per lane and load
+        const uint4 *g = reinterpret_cast<const uint4 *>(qtop + (size_t)(tree_lo + t) * (2 * NBOT));
+        pf0 = g[0 * 64 + lane];
+        pf1 = g[1 * 64 + lane];
+        pf2 = g[2 * 64 + lane];
+        pf3 = g[3 * 64 + lane];
     };
     auto commit_top = [&]() {
         uint4 *s = reinterpret_cast<uint4 *>(slot);
@@ -387,52 +406,51 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
         uint32_t pos[K];  // LDS byte address of this lane's row in feature column 0 of region k
 #pragma unroll
         for (int k = 0; k < K; ++k) pos[k] = (uint32_t)(k * kRegBytes) + 2u * (uint32_t)qreg_pos(lane);
-        for (int t = wave; t < num_trees && !dead; t += NWALK) {
-            const bool more = t + NWALK < num_trees;
-            if (more) prefetch_top(t + NWALK);
-            const uint2 *root = qnodes + ctrees[tree_lo + t];
-            uint2 n[K];
-            uint32_t curr[K];
-            {
-                const uint2 r1 = slot[1];  // the root; position 0 is padding
+        // State of the PREVIOUS tree of this walker (t_p): per chain what lies below the top -- a leaf value, or (act) the
+        // block where the walk goes on, gathered into a / b.  Its walk below the top is advanced, one block = two levels at
+        // a time, BETWEEN the levels of the current tree's top walk: the gathers of the next blocks fly under three LDS
+        // levels of the other tree (software pipeline; a block step costs its compute, not its round trip to L2).
+        int t_p = -1;
+        const uint4 *tb_p = qblocks;
+        uint32_t entry_p[K] = {}, act_p[K] = {}, cpos_p[K] = {};
+        uint4 a_p[K] = {}, b_p[K] = {};
+        auto deep_step = [&]() -> bool {  // false: no lane of the wave was still under way
+            uint32_t open = act_p[0];
 #pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    n[k] = r1;
-                    curr[k] = 1u;
+            for (int k = 1; k < K; ++k) open |= act_p[k];
+            if (__ballot(open != 0u) == 0ull) return false;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                // per chain, and only a chain that still has a lane under way (the long tails are one or two lanes of one
+                // chain); a finished lane of such a chain computes on stale registers and keeps its value
+                if (__ballot(act_p[k] != 0u) == 0ull) continue;
+                const bool c0 = q_go_right<MS, true>(q_xread<true, true, 7>(nullptr, a_p[k].x, pos[k]), a_p[k].x);
+                const uint32_t n1 = c0 ? a_p[k].z : a_p[k].y;
+                const bool c1 = q_go_right<MS, true>(q_xread<true, true, 7>(nullptr, n1, pos[k]), n1);
+                const uint32_t lo = c0 ? b_p[k].z : b_p[k].x, hi = c0 ? b_p[k].w : b_p[k].y;
+                const uint32_t j = (c0 ? 2u : 0u) + (c1 ? 1u : 0u);
+                const bool on = act_p[k] != 0u;
+                const bool cont = ((a_p[k].w >> j) & 1u) != 0u;
+                if (WRITE_LEAF) {
+                    if (on && !cont) cpos_p[k] = qblkpos[4 * ((size_t)qblkoff[tree_lo + t_p] + entry_p[k]) + j];
+                }
+                entry_p[k] = on ? (c1 ? hi : lo) : entry_p[k];  // the next block, or the leaf value
+                act_p[k] = (on && cont) ? 1u : 0u;
+                if (act_p[k] != 0u) {  // the tree's blocks from SGPRs, the block's byte offset (32 bits) from a VGPR
+                    const uint4 *bp = reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(tb_p) + (entry_p[k] << 5));
+                    a_p[k] = bp[0];
+                    b_p[k] = bp[1];
                 }
             }
-            for (;;) {  // create() guarantees children after their parent and inside the tree: the walks terminate
-                uint32_t open = n[0].y;
-#pragma unroll
-                for (int k = 1; k < K; ++k) open |= n[k].y;
-                if (__ballot(open != 0u) == 0ull) break;  // every chain of the wave holds its leaf
-                uint32_t xc[K];
-                uint4 pr[K];
-#pragma unroll
-                for (int k = 0; k < K; ++k) {  // a finished chain reads some code and the padding pair: harmless
-                    xc[k] = q_xread<true, true, 7>(nullptr, n[k].x, pos[k]);
-                    pr[k] = *reinterpret_cast<const uint4 *>(&slot[min(n[k].y, (uint32_t)(kSTop - 2))]);
-                }
-#pragma unroll
-                for (int k = 0; k < K; ++k)  // children below the top: from global memory, for the lanes that are there
-                    if (__ballot(n[k].y >= (uint32_t)kSTop) != 0ull) {
-                        if (n[k].y >= (uint32_t)kSTop) pr[k] = *reinterpret_cast<const uint4 *>(root + n[k].y);
-                    }
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const bool r = q_go_right<MS, true>(xc[k], n[k].x);
-                    const bool live = n[k].y != 0u;
-                    const uint32_t cx = r ? pr[k].z : pr[k].x, cy = r ? pr[k].w : pr[k].y;
-                    if (WRITE_LEAF) curr[k] = live ? n[k].y + (r ? 1u : 0u) : curr[k];
-                    n[k].x = live ? cx : n[k].x;
-                    n[k].y = live ? cy : 0u;
-                }
-            }
+            return true;
+        };
+        auto publish = [&]() {  // leaf values of tree t_p to the consumer (and its leaf indices out)
+            const int t = t_p;
             if (WRITE_LEAF) {
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     const size_t row = row0 + k * 64 + lane;
-                    if (row < rows) leaf_out[row * (size_t)total_trees + tree_lo + t] = corig[ctrees[tree_lo + t] + curr[k]];
+                    if (row < rows) leaf_out[row * (size_t)total_trees + tree_lo + t] = corig[ctrees[tree_lo + t] + cpos_p[k]];
                 }
             }
             if (t >= RING) {  // ring entry still in use by tree t - RING?
@@ -447,10 +465,87 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
             }
             const int e = t % RING;
 #pragma unroll
-            for (int k = 0; k < K; ++k) ring_vals[e * TR + k * 64 + lane] = __uint_as_float(n[k].x);
+            for (int k = 0; k < K; ++k) ring_vals[e * TR + k * 64 + lane] = __uint_as_float(entry_p[k]);
             asm volatile("" ::: "memory");  // values before the flag: a wave's LDS operations are performed in issue order
             if (lane == 0) lds_flag_store(&ring_ready[e], (uint32_t)(t + 1));
+        };
+        for (int t = wave; t < num_trees && !dead; t += NWALK) {
+            const bool more = t + NWALK < num_trees;
+            if (more) prefetch_top(t + NWALK);
+            uint32_t i[K], node[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                i[k] = 1u;
+                node[k] = slot[1];
+            }
+            {   // level 0: every chain is at the root -- one read of its child pair serves them all
+                const uint2 pr0 = *reinterpret_cast<const uint2 *>(&slot[2]);
+                uint32_t xc0[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) xc0[k] = q_xread<true, true, 7>(nullptr, node[k], pos[k]);
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const uint64_t cm = q_right_mask<MS, true>(xc0[k], node[k]);
+                    i[k] = q_descend(i[k], cm);
+                    node[k] = __builtin_amdgcn_inverse_ballot_w64(cm) ? pr0.y : pr0.x;
+                }
+            }
+            for (int l = 1; l < kSQLevels - 1; ++l) {  // both children come with one ds_read_b64 beside the code read
+                uint32_t xc[K];
+                uint2 pr[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    xc[k] = q_xread<true, true, 7>(nullptr, node[k], pos[k]);
+                    pr[k] = *reinterpret_cast<const uint2 *>(&slot[2 * i[k]]);
+                }
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const uint64_t cm = q_right_mask<MS, true>(xc[k], node[k]);
+                    i[k] = q_descend(i[k], cm);
+                    node[k] = __builtin_amdgcn_inverse_ballot_w64(cm) ? pr[k].y : pr[k].x;
+                }
+                if (t_p >= 0 && (l == 3 || l == 6)) (void)deep_step();  // the previous tree, below its top
+            }
+            uint32_t entry[K];  // what lies below the last level's branch: a leaf value, or the block where the walk goes on
+            uint32_t act[K];    // 1: this chain's walk goes on below the top
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const uint32_t xc = q_xread<true, true, 7>(nullptr, node[k], pos[k]);
+                const uint64_t cm = q_right_mask<MS, true>(xc, node[k]);
+                i[k] = q_descend(i[k], cm);  // NBOT .. 2 NBOT - 1
+                act[k] = (__builtin_amdgcn_inverse_ballot_w64(cm) ? node[k] >> 2 : node[k] >> 1) & 1u;
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) entry[k] = slot[i[k]];
+            uint32_t cpos[K];  // compact position of the leaf (leaf-index output only)
+            if (WRITE_LEAF) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) cpos[k] = qbotpos[(size_t)(tree_lo + t) * NBOT + (i[k] - NBOT)];
+            }
+            if (t_p >= 0) {  // whatever is left of the previous tree's walk, then hand it over
+                while (deep_step()) {
+                }
+                publish();
+            }
+            t_p = t;
+            tb_p = qblocks + 2 * (size_t)qblkoff[tree_lo + t];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                entry_p[k] = entry[k];
+                act_p[k] = act[k];
+                if (WRITE_LEAF) cpos_p[k] = cpos[k];
+                if (act[k] != 0u) {  // this tree's first blocks: in flight while the next top is walked
+                    const uint4 *bp = reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(tb_p) + (entry[k] << 5));
+                    a_p[k] = bp[0];
+                    b_p[k] = bp[1];
+                }
+            }
             if (more) commit_top();  // this wave's reads of its slot are done (in-order LDS)
+        }
+        if (t_p >= 0 && !dead) {
+            while (deep_step()) {
+            }
+            publish();
         }
     };
     // chunk_flags[c] != 0 <=> the quantise pass met a missing value in rows [c, c+1) << cshift; a tile can straddle two chunks
@@ -461,7 +556,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
     if (dead && lane == 0) atomicOr(error_flag, 1);
 }
 
-bool sparse_q_available(const tahoe_forest *f) { return f->sp && f->sp->qnodes && f->q; }
+bool sparse_q_available(const tahoe_forest *f) { return f->sp && f->sp->qtop && f->q; }
 
 template <int NWALK, int K, int RING>
 static void sparse_q_launch_form(tahoe_forest *f, const tahoe_qgroup &g, float *sums, const float *sums_in, uint32_t *leaf_out,
@@ -472,12 +567,12 @@ static void sparse_q_launch_form(tahoe_forest *f, const tahoe_qgroup &g, float *
     if (grid == 0) return;
     const int lds = (int)qreg_lds_for(K, NWALK, RING);
     if (leaf_out)
-        hipLaunchKernelGGL((sparse_q_kernel<NWALK, true, K, RING>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, f->q->xq, sp->qnodes,
-                           sp->ctrees, sp->corig, sums, leaf_out, rows_end, f->p.num_cols, g.tree_lo, g.num_trees, f->p.num_trees,
+        hipLaunchKernelGGL((sparse_q_kernel<NWALK, true, K, RING>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, f->q->xq, sp->qtop, sp->qblocks,
+                           sp->qblkoff, sp->qbotpos, sp->qblkpos, sp->ctrees, sp->corig, sums, leaf_out, rows_end, f->p.num_cols, g.tree_lo, g.num_trees, f->p.num_trees,
                            f->q->chunk_flags, f->error_flag, sums_in, cshift, row_begin);
     else
-        hipLaunchKernelGGL((sparse_q_kernel<NWALK, false, K, RING>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, f->q->xq, sp->qnodes,
-                           sp->ctrees, sp->corig, sums, leaf_out, rows_end, f->p.num_cols, g.tree_lo, g.num_trees, f->p.num_trees,
+        hipLaunchKernelGGL((sparse_q_kernel<NWALK, false, K, RING>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, f->q->xq, sp->qtop, sp->qblocks,
+                           sp->qblkoff, sp->qbotpos, sp->qblkpos, sp->ctrees, sp->corig, sums, leaf_out, rows_end, f->p.num_cols, g.tree_lo, g.num_trees, f->p.num_trees,
                            f->q->chunk_flags, f->error_flag, sums_in, cshift, row_begin);
 }
 
@@ -493,7 +588,7 @@ static tahoe_status sparse_q_launch(tahoe_forest *f, float *sums, uint32_t *leaf
     if (rs != TAHOE_OK) return rs;
     size_t rows3 = 0;
     int chains = 2;
-    qreg_plan(rows, f->num_cus, f->knob_qring_chains, &rows3, &chains);
+    qreg_plan(rows, f->num_cus, f->knob_qring_chains, &rows3, &chains, 161);  // K5: 0.555 ms per wave of 192-row tiles, 0.344 of 128
     bool first = true;
     for (const tahoe_qgroup &g : q->groups) {
         TAHOE_HIP_TRY(hipMemsetAsync(q->chunk_flags, 0, q->n_chunk_flags * sizeof(uint32_t), stream));
@@ -592,7 +687,8 @@ void sparse_destroy(tahoe_forest *f)
     if (f->sp->cnodes) (void)hipFree(f->sp->cnodes);
     if (f->sp->ctrees) (void)hipFree(f->sp->ctrees);
     if (f->sp->corig) (void)hipFree(f->sp->corig);
-    if (f->sp->qnodes) (void)hipFree(f->sp->qnodes);
+    for (void *p : {(void *)f->sp->qtop, (void *)f->sp->qblocks, (void *)f->sp->qblkoff, (void *)f->sp->qbotpos, (void *)f->sp->qblkpos})
+        if (p) (void)hipFree(p);
     delete f->sp;
     f->sp = nullptr;
 }
@@ -693,9 +789,113 @@ static tahoe_status sparse_q_build(tahoe_forest *f, const std::vector<uint2> &cn
         }
         G = std::max(G + 1, (size_t)((double)G * worst / kQMaxTable + 0.999));
     }
+    // ---- the tops (first kSQLevels levels of every tree as a complete heap) and the blocks below them (see sparse_q_kernel) ----
+    constexpr uint32_t NBOT = 1u << kSQLevels;
+    std::vector<uint32_t> h_top(T * 2 * NBOT, 0u), h_botpos(T * NBOT, 0u);
+    std::vector<std::vector<uint4>> tree_blocks(T);      // two uint4 per block
+    std::vector<std::vector<uint32_t>> tree_blkpos(T);   // four compact positions per block
+    parallel_for(T, 8, [&](size_t t_lo, size_t t_hi) {
+        struct Item {
+            uint32_t h, p;  // heap position (1-based) or block index; compact position inside the tree
+        };
+        std::vector<Item> stack, work;
+        for (size_t t = t_lo; t < t_hi; ++t) {
+            const uint2 *tn = &qn[(size_t)ct[t]];
+            uint32_t *top = &h_top[t * 2 * NBOT], *bot = &h_botpos[t * NBOT];
+            std::vector<uint4> &blk = tree_blocks[t];
+            std::vector<uint32_t> &bpos = tree_blkpos[t];
+            work.clear();
+            auto new_block = [&](uint32_t p) {  // block whose first node is the inner node at compact position p
+                const uint32_t idx = (uint32_t)(blk.size() / 2);
+                blk.resize(blk.size() + 2);
+                bpos.resize(bpos.size() + 4);
+                work.push_back(Item{idx, p});
+                return idx;
+            };
+            stack.assign(1, Item{1u, 1u});  // the root sits at compact position 1
+            while (!stack.empty()) {
+                const Item it = stack.back();
+                stack.pop_back();
+                const uint2 c = tn[it.p];
+                if (it.h >= NBOT) {  // below the last level of the top
+                    bot[it.h - NBOT] = it.p;
+                    if (c.y == 0u)
+                        top[it.h] = c.x;  // a leaf: its value
+                    else {
+                        top[it.h] = new_block(it.p);  // the walk goes on; flagged in the parent's word (bit 1: left, 2: right)
+                        top[it.h >> 1] |= (it.h & 1u) ? 4u : 2u;
+                    }
+                } else if (c.y == 0u) {  // early leaf: padding nodes (word 0) down to the last level, the value below all of them
+                    for (uint32_t lo = it.h, n = 1u; lo < 2 * NBOT; lo *= 2u, n *= 2u)
+                        for (uint32_t h = lo; h < lo + n; ++h) {
+                            top[h] = h >= NBOT ? c.x : 0u;
+                            if (h >= NBOT) bot[h - NBOT] = it.p;
+                        }
+                } else {
+                    top[it.h] = c.x;
+                    stack.push_back(Item{2u * it.h + 1u, c.y + 1u});
+                    stack.push_back(Item{2u * it.h, c.y});
+                }
+            }
+            for (size_t w = 0; w < work.size(); ++w) {  // grows while it runs: a block's branches that go on get blocks too
+                const Item it = work[w];
+                const uint2 n0 = tn[it.p];
+                uint32_t word[2] = {0u, 0u}, e[4], ep[4], flags = 0u;
+                for (uint32_t sd = 0; sd < 2; ++sd) {
+                    const uint32_t cp = n0.y + sd;
+                    const uint2 c = tn[cp];
+                    if (c.y == 0u) {  // the child is a leaf: padding word, its value below both branches
+                        e[2 * sd] = e[2 * sd + 1] = c.x;
+                        ep[2 * sd] = ep[2 * sd + 1] = cp;
+                        continue;
+                    }
+                    word[sd] = c.x;
+                    for (uint32_t g = 0; g < 2; ++g) {
+                        const uint32_t gp = c.y + g;
+                        const uint2 gc = tn[gp];
+                        ep[2 * sd + g] = gp;
+                        if (gc.y == 0u)
+                            e[2 * sd + g] = gc.x;
+                        else {
+                            e[2 * sd + g] = new_block(gp);
+                            flags |= 1u << (2 * sd + g);
+                        }
+                    }
+                }
+                blk[2 * (size_t)it.h] = make_uint4(n0.x, word[0], word[1], flags);
+                blk[2 * (size_t)it.h + 1] = make_uint4(e[0], e[1], e[2], e[3]);
+                for (int j = 0; j < 4; ++j) bpos[4 * (size_t)it.h + j] = ep[j];
+            }
+        }
+    });
+    std::vector<int32_t> h_blkoff(T + 1, 0);
+    {
+        size_t total = 0;
+        for (size_t t = 0; t < T; ++t) {
+            h_blkoff[t] = (int32_t)total;
+            total += tree_blocks[t].size() / 2;
+            if (total > 0x3fffffffu) {  // block indices stay 32-bit with room to spare
+                qring_destroy(f);
+                return TAHOE_OK;
+            }
+        }
+        h_blkoff[T] = (int32_t)total;
+    }
+    std::vector<uint4> h_blocks((size_t)h_blkoff[T] * 2);
+    std::vector<uint32_t> h_blkpos((size_t)h_blkoff[T] * 4);
+    parallel_for(T, 64, [&](size_t t_lo, size_t t_hi) {
+        for (size_t t = t_lo; t < t_hi; ++t) {
+            std::copy(tree_blocks[t].begin(), tree_blocks[t].end(), h_blocks.begin() + (size_t)h_blkoff[t] * 2);
+            std::copy(tree_blkpos[t].begin(), tree_blkpos[t].end(), h_blkpos.begin() + (size_t)h_blkoff[t] * 4);
+        }
+    });
     hipError_t e;
-    if ((e = q_upload(&sp->qnodes, qn.data(), qn.size(), &f->device_bytes)) != hipSuccess)
-        return fail(TAHOE_ERR_HIP, "sparse_q_build: qnodes failed: %s", hipGetErrorString(e));
+    auto bad = [&](const char *what) { return fail(TAHOE_ERR_HIP, "sparse_q_build: %s failed: %s", what, hipGetErrorString(e)); };
+    if ((e = q_upload(&sp->qtop, h_top.data(), h_top.size(), &f->device_bytes)) != hipSuccess) return bad("qtop");
+    if ((e = q_upload(&sp->qbotpos, h_botpos.data(), h_botpos.size(), &f->device_bytes)) != hipSuccess) return bad("qbotpos");
+    if ((e = q_upload(&sp->qblocks, h_blocks.data(), h_blocks.size(), &f->device_bytes)) != hipSuccess) return bad("qblocks");
+    if ((e = q_upload(&sp->qblkpos, h_blkpos.data(), h_blkpos.size(), &f->device_bytes)) != hipSuccess) return bad("qblkpos");
+    if ((e = q_upload(&sp->qblkoff, h_blkoff.data(), h_blkoff.size(), &f->device_bytes)) != hipSuccess) return bad("qblkoff");
     for (const void *k : {(const void *)&sparse_q_kernel<kReg3Walkers, false, 3, kReg3Ring>, (const void *)&sparse_q_kernel<kReg3Walkers, true, 3, kReg3Ring>,
                           (const void *)&sparse_q_kernel<15, false, 2, kQRing>, (const void *)&sparse_q_kernel<15, true, 2, kQRing>})
         if ((e = allow_max_lds(k, f->lds_limit)) != hipSuccess)

@@ -1,4 +1,4 @@
-"""Soak: many back-to-back predicts of the ring kernels (K3 QRING, K2 wide form, K5 sparse), then tahoe_forest_check
+"""Soak: many back-to-back predicts of the ring kernels (K3 QRING, K2 wide form, K5 sparse: quantised and float32), then tahoe_forest_check
 (a bounded LDS wait that ever timed out raises) and a bit-for-bit comparison of the last result with the first."""
 import os, sys, time
 import numpy as np, torch
@@ -29,7 +29,9 @@ soak("K3 qring", f, x, 1000)
 f.close()
 sn, tr = ta.capi.synth_sparse_forest(2000, 256, 4, 24, 0.32, 65535, 44)
 f = ta.capi.SparseForest(sn, tr, 256, missing=-999.0)
-soak("K5 sparse ring", f, x[:200_000].contiguous(), 100)
+soak("K5 sparse, quantised ring", f, x[:200_000].contiguous(), 100)
+f.set_strategy(ta.STRATEGY_TILEBLOCK)
+soak("K5 sparse, float32 ring", f, x[:200_000].contiguous(), 50)
 f.close()
 del x
 x = torch.from_numpy(ta.synth_data(100_000, 3072, seed=22)).cuda()
