@@ -200,3 +200,56 @@ def test_sparse_quantised_walk_tree_groups_and_tile_plans(ta):
         assert np.array_equal(leaf.cpu().numpy().view(np.uint32), leaf2), chains
         assert np.array_equal(sums.cpu().numpy().view(np.uint32), want2.view(np.uint32)), chains
         f2.close()
+
+
+@pytest.mark.gpu
+def test_sparse_quantised_walk_vines_odd_widths_host_batches(ta):
+    """Shapes that stress the layout of the quantised sparse walk: vines (every inner node has one leaf child: 40 levels, i.e.
+    a long chain of two-level blocks below the 9-level top, early-leaf padding inside top and blocks), a tree that is one
+    leaf, odd num_cols (single-feature quantise kernels) and num_cols = 1; predictions through the host-batch pipeline."""
+    import torch
+
+    rng = np.random.default_rng(5)
+    LEAF = np.int32(-2**31)
+
+    def vine(depth, cols, right_goes_on):
+        """`depth` inner nodes in a chain: one child of each is a leaf, the other the next inner node (children adjacent, after
+        their parent, left_idx relative to the root)"""
+        n = np.zeros(2 * depth + 1, dtype=ta.capi.SPARSE_NODE_DTYPE)
+        pos, nxt = 0, 1
+        for d in range(depth):
+            n["val"][pos] = rng.choice([-0.5, 0.0, -0.0, 0.25, np.nan, np.inf]) if d % 7 == 3 else rng.uniform(-1, 1)
+            n["bits"][pos] = int(rng.integers(0, cols)) | (int(rng.integers(0, 2)) << 30)
+            n["left_idx"][pos] = nxt
+            go, stop = (nxt + 1, nxt) if right_goes_on else (nxt, nxt + 1)
+            n["val"][stop], n["bits"][stop] = rng.uniform(-2, 2), LEAF
+            if d == depth - 1:
+                n["val"][go], n["bits"][go] = rng.uniform(-2, 2), LEAF
+            pos, nxt = go, nxt + 2
+        return n
+
+    for cols in (1, 7, 255):
+        parts = [vine(40, cols, True), vine(33, cols, False), vine(9, cols, True), vine(10, cols, False), vine(1, cols, True)]
+        one_leaf = np.zeros(1, dtype=ta.capi.SPARSE_NODE_DTYPE)
+        one_leaf["val"], one_leaf["bits"] = 4.5, LEAF
+        parts.insert(2, one_leaf)
+        bushy, btr = ta.capi.synth_sparse_forest(12, cols, 3, 13, 0.25, 65535, 300 + cols)
+        roots = np.cumsum([0] + [len(p) for p in parts]).astype(np.int32)
+        nodes = np.concatenate(parts + [bushy])
+        trees = np.concatenate([roots[:-1], btr + roots[-1]]).astype(np.int32)
+        rows = 777
+        data = ta.synth_data(rows, cols, seed=400 + cols, missing_prob=0.08, missing=MISSING, nan_prob=0.04)
+        want, want_leaf = oracle.sparse_predict(nodes, trees, data, MISSING, want_leaf=True, threads=4)
+        f = ta.capi.SparseForest(nodes, trees, cols, missing=MISSING)
+        x = torch.from_numpy(data).cuda()
+        for strategy in (ta.STRATEGY_QRING, ta.STRATEGY_TILEBLOCK):
+            f.set_strategy(strategy)
+            leaf, sums = f.predict_leaf_idx(x)
+            f.check()
+            assert np.array_equal(sums.cpu().numpy().view(np.uint32), want.view(np.uint32)), (cols, strategy)
+            assert np.array_equal(leaf.cpu().numpy().view(np.uint32), want_leaf), (cols, strategy)
+        f.set_strategy(ta.STRATEGY_QRING)
+        host = f.predict_host(data, chunk_rows=256)  # chunked upload + traversal
+        f.check()
+        assert np.array_equal(host.view(np.uint32), want.view(np.uint32)), cols
+        f.close()
