@@ -120,8 +120,8 @@ enum {
  * in LDS, walker waves + ordered ring consumer (trees of <= 65535 nodes), QRING = the same on rank-quantised
  * data: 192- / 128-row u16 tiles, three / two chains per lane, the first 9 levels of each tree as a complete
  * heap in LDS, 32-byte two-level blocks below (num_cols <= 256; tree groups as for dense forests).  AUTO
- * takes QRING when 20 x trees >= 13 x num_cols (enough walking per feature value to pay the quantise pass),
- * else TILEBLOCK, else what fits. */
+ * takes QRING when 20 x trees >= 13 x num_cols (enough walking per feature value to pay the quantise pass)
+ * and the batch has >= 64 rows per CU, else TILEBLOCK, else what fits. */
 
 typedef struct tahoe_forest tahoe_forest; /* opaque */
 

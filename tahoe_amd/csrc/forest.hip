@@ -697,16 +697,18 @@ static int tilering_rows(const tahoe_forest *f)
     return 0;
 }
 
-static int resolve_strategy(const tahoe_forest *f, size_t /*rows*/)
+static int resolve_strategy(const tahoe_forest *f, size_t rows)
 {
     if (f->sp) {  // sparse handle: QRING = quantised 192-row tile + tree tops in LDS, TILEBLOCK = 64-row float32 tile + tree
                   // tops, ROWTILE = tile only, DIRECT = neither
         if (f->strategy == TAHOE_STRATEGY_DIRECT) return TAHOE_STRATEGY_DIRECT;
         if (f->strategy == TAHOE_STRATEGY_ROWTILE) return TAHOE_STRATEGY_ROWTILE;
         // the quantise pass over rows x cols pays when there is walking to do per feature value (the dense rule, with ten
-        // levels standing in for the unknown path length)
+        // levels standing in for the unknown path length) and the batch gives every CU a 128-row tile or so -- below that
+        // the float32 kernel's 64-row tiles fill more of the chip (tools/selector_sparse.py, profiles/r02/selector_sparse.json)
         if (sparse_q_available(f) &&
-            (f->strategy == TAHOE_STRATEGY_QRING || (f->strategy == TAHOE_STRATEGY_AUTO && 20LL * f->p.num_trees >= 13LL * f->p.num_cols)))
+            (f->strategy == TAHOE_STRATEGY_QRING ||
+             (f->strategy == TAHOE_STRATEGY_AUTO && 20LL * f->p.num_trees >= 13LL * f->p.num_cols && rows >= (size_t)64 * (size_t)std::max(f->num_cus, 1))))
             return TAHOE_STRATEGY_QRING;
         if (sparse_top_waves(f) > 0) return TAHOE_STRATEGY_TILEBLOCK;
         return sparse_tile_fits(f) ? TAHOE_STRATEGY_ROWTILE : TAHOE_STRATEGY_DIRECT;

@@ -92,7 +92,9 @@ def test_sparse_walk_on_gpu(ta):
             strategies.append(ta.STRATEGY_QRING)
             f.set_strategy(ta.STRATEGY_AUTO)  # QRING when there is enough walking per feature value to pay the quantise pass
             n_trees = len(tr_)
-            assert f.get_strategy(len(data_)) == (ta.STRATEGY_QRING if 20 * n_trees >= 13 * cols else ta.STRATEGY_TILEBLOCK)
+            assert f.get_strategy(len(data_)) == ta.STRATEGY_TILEBLOCK  # a small batch: the 64-row tiles fill more of the chip
+            big = 64 * f.info().num_cus
+            assert f.get_strategy(big) == (ta.STRATEGY_QRING if 20 * n_trees >= 13 * cols else ta.STRATEGY_TILEBLOCK)
         else:
             with pytest.raises(ta.TahoeError):
                 f.set_strategy(ta.STRATEGY_QRING)
@@ -194,7 +196,8 @@ def test_sparse_quantised_walk_tree_groups_and_tile_plans(ta):
             f2 = ta.capi.SparseForest(sn2, tr2, 256, missing=MISSING)
         finally:
             os.environ.pop("TAHOE_QRING_CHAINS", None)
-        assert f2.get_strategy(3000) == ta.STRATEGY_QRING
+        assert f2.get_strategy(1_000_000) == ta.STRATEGY_QRING
+        f2.set_strategy(ta.STRATEGY_QRING)
         leaf, sums = f2.predict_leaf_idx(x2)
         f2.check()
         assert np.array_equal(leaf.cpu().numpy().view(np.uint32), leaf2), chains
