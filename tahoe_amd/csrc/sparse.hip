@@ -9,12 +9,18 @@
 // what predict_on_cpu predicts for the dense original, which is the check the reference's own sparse
 // harness makes (BaseTahoeTest.h:836).
 //
-// Kernels: lane = row, the four waves of a workgroup split the trees round-robin, leaf values cross LDS
-// once per round of four trees and are added by the row's owner lane in tree order (float32 sums bit-equal
-// to a sequential CPU sum).  A walk is a chain of dependent 12-byte node gathers from L2 / Infinity Cache;
-// lanes that have reached their leaf idle until the longest path of the wave ends (wave divergence is
-// inherent to irregular trees).  With TILE the 64 rows sit feature-major in LDS (any per-lane fid is
-// bank-conflict free), else features come from global memory.
+// Kernels, fastest first (strategy on a sparse handle):
+//   sparse_q_kernel    QRING      rank-quantised codes (quantize.hip), 192- / 128-row region tiles, 3 / 2 chains per lane, the
+//                                 first 9 levels of each tree as a complete heap in LDS, 32-byte two-level blocks below, ring
+//                                 consumer; num_cols <= 256 (K5: 2.5 ms)
+//   sparse_top_kernel  TILEBLOCK  64-row float32 tile + the first 512 nodes of each tree (breadth-first, children paired) in
+//                                 LDS, ring consumer (K5: 4.9 ms)
+//   sparse_kernel      ROWTILE / DIRECT   the 12-byte nodes as given: lane = row, the four waves of a workgroup split the
+//                                 trees round-robin, leaf values cross LDS once per round of four trees and are added by
+//                                 the row's owner lane in tree order; with TILE the 64 rows sit feature-major in LDS, else
+//                                 features come from global memory (K5: 17 / 23 ms)
+// Every form adds the leaf values in tree order: float32 sums bit-equal to a sequential CPU sum.  Lanes that have reached
+// their leaf idle until the longest path of the wave ends (wave divergence is inherent to irregular trees).
 #include <algorithm>
 #include <cstring>
 #include <new>
