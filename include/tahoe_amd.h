@@ -106,7 +106,10 @@ enum {
                                     one 32-byte block per walk; two barriers per round of 4 trees */
     TAHOE_STRATEGY_TILERING = 4, /* TILEBLOCK's data path with decoupled waves: walker waves with
                                     private tops, no barrier in the tree loop, one consumer wave adds
-                                    leaf values in tree order through an LDS ring */
+                                    leaf values in tree order through an LDS ring.  num_cols > 512: the
+                                    wide-row form -- 32- / 16- / 8-row float32 tiles staged as they lie in
+                                    memory, 2 / 4 / 8 trees per wave, 48-byte bottom blocks; AUTO's choice
+                                    there when 2 x trees x depth < 13 x num_cols (no quantise pass) */
     TAHOE_STRATEGY_QRING = 5     /* TILERING on rank-quantised data: features and thresholds become
                                     exact 16-bit ranks (a per-predict quantise pass), 128-row u16 tile,
                                     4-byte nodes, up to 15 walker waves x 2 chains; rows too wide for that

@@ -721,10 +721,10 @@ static int resolve_strategy(const tahoe_forest *f, size_t rows)
     // on (--holdout) it picks the fastest strategy on 8 and stays within 1.16x on the other two.
     const bool shallow = f->depth <= 4 && rowtile_fits(f);
     const bool little_work = 2LL * f->p.num_trees * f->depth < 13LL * f->p.num_cols &&
-                             (tilering_rows(f) > 0 || tileblock_rows(f) > 0 || rowtile_fits(f));
+                             (tilering_rows(f) > 0 || widef_rows(f) > 0 || tileblock_rows(f) > 0 || rowtile_fits(f));
     if (shallow) return TAHOE_STRATEGY_ROWTILE;
     if (qring_walkers(f) > 0 && !little_work) return TAHOE_STRATEGY_QRING;
-    if (tilering_rows(f) > 0) return TAHOE_STRATEGY_TILERING;
+    if (tilering_rows(f) > 0 || widef_rows(f) > 0) return TAHOE_STRATEGY_TILERING;
     if (tileblock_rows(f) > 0) return TAHOE_STRATEGY_TILEBLOCK;
     return rowtile_fits(f) ? TAHOE_STRATEGY_ROWTILE : TAHOE_STRATEGY_DIRECT;
 }
@@ -806,10 +806,13 @@ static tahoe_status launch_traversal(tahoe_forest *f, float *sums, uint32_t *lea
         const tahoe_status qs = qring_launch(f, sums, leaf_out, data, rows, stream, timed ? f->ev_mid[f->prof_count] : nullptr, sums_in);
         mid_recorded = timed;
         if (qs != TAHOE_OK) return qs;
+    } else if (strategy == TAHOE_STRATEGY_TILERING && tilering_rows(f) == 0 && widef_rows(f) > 0) {
+        const tahoe_status ws = widef_launch(f, sums, leaf_out, data, rows, stream, sums_in);  // rows too wide for a 64-row tile
+        if (ws != TAHOE_OK) return ws;
     } else if (strategy == TAHOE_STRATEGY_TILERING) {
         const int tr = tilering_rows(f);
         if (tr == 0)
-            return fail(TAHOE_ERR_UNSUPPORTED, "TILERING needs num_cols <= %d and a 64-row tile that fits %d B of LDS",
+            return fail(TAHOE_ERR_UNSUPPORTED, "TILERING needs a 64-row tile (num_cols <= %d) or an 8-row tile that fits %d B of LDS",
                         kBlockMaxCols, f->lds_limit);
         if (tr == 128)
             launch_tilering<128, 4>(f, sums, leaf_out, sums_in, data, rows, stream, vec4_ok);
@@ -1152,6 +1155,13 @@ tahoe_status tahoe_forest_create_ex(tahoe_forest **out, const tahoe_dense_node *
             return qs;
         }
     }
+    if (tilering_rows(f) == 0 && tileblock_rows(f) == 0) {  // no 64-row float32 tile kernel for this shape: the wide-row form
+        const tahoe_status ws = widef_build(f, h_inner, h_leaf);
+        if (ws != TAHOE_OK) {
+            tahoe_forest_destroy(f);
+            return ws;
+        }
+    }
     if (f->has_blocks && tilering_lds_bytes(f, 64) <= f->lds_limit) {
         if ((e = allow_max_lds(reinterpret_cast<const void *>(&tilering_kernel<64, 8, false>), f->lds_limit)) != hipSuccess) return bail(e, "hipFuncSetAttribute(tilering)");
         if ((e = allow_max_lds(reinterpret_cast<const void *>(&tilering_kernel<64, 8, true>), f->lds_limit)) != hipSuccess) return bail(e, "hipFuncSetAttribute(tilering)");
@@ -1180,6 +1190,7 @@ void tahoe_forest_destroy(tahoe_forest *f)
     pipeline_destroy(f);
     qring_destroy(f);
     sparse_destroy(f);
+    widef_destroy(f);
     for (hipEvent_t e : f->ev_start) (void)hipEventDestroy(e);
     for (hipEvent_t e : f->ev_mid) (void)hipEventDestroy(e);
     for (hipEvent_t e : f->ev_stop) (void)hipEventDestroy(e);
@@ -1251,8 +1262,8 @@ tahoe_status tahoe_forest_set_strategy(tahoe_forest *f, int strategy)
     if (strategy == TAHOE_STRATEGY_TILEBLOCK && tileblock_rows(f) == 0)
         return fail(TAHOE_ERR_UNSUPPORTED, "TILEBLOCK needs num_cols <= %d and a 64-row tile that fits %d B of LDS",
                     kBlockMaxCols, f->lds_limit);
-    if (strategy == TAHOE_STRATEGY_TILERING && tilering_rows(f) == 0)
-        return fail(TAHOE_ERR_UNSUPPORTED, "TILERING needs num_cols <= %d and a 64-row tile that fits %d B of LDS",
+    if (strategy == TAHOE_STRATEGY_TILERING && tilering_rows(f) == 0 && widef_rows(f) == 0)
+        return fail(TAHOE_ERR_UNSUPPORTED, "TILERING needs a 64-row tile (num_cols <= %d) or an 8-row tile that fits %d B of LDS",
                     kBlockMaxCols, f->lds_limit);
     if (strategy == TAHOE_STRATEGY_QRING && qring_walkers(f) == 0)
         return fail(TAHOE_ERR_UNSUPPORTED,
@@ -1310,7 +1321,7 @@ tahoe_status tahoe_forest_get_info(const tahoe_forest *f, tahoe_forest_info *inf
     info->qring_walkers = qring_walkers(f);
     info->qring_lds_bytes = (int)qring_lds_bytes(f);
     info->qring_groups = qring_groups(f);
-    info->ring_rows = tilering_rows(f);
+    info->ring_rows = tilering_rows(f) ? tilering_rows(f) : widef_rows(f);
     info->tilering_lds_bytes = info->ring_rows ? (int)tilering_lds_bytes(f, info->ring_rows) : 0;
     info->qring_tile_rows = info->qring_walkers == 0 ? 0 : qwide_rows(f) ? qwide_rows(f) : qring_regions(f) ? 192 : qring_lds_tile(f) ? 128 : 0;
     info->relayout = f->relayout ? 1 : 0;

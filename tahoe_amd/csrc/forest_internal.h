@@ -11,6 +11,7 @@
 struct tahoe_qstate;  // quantised views + workspace, owned by qring.hip
 struct tahoe_sstate;  // sparse (irregular) forest, owned by sparse.hip
 struct tahoe_pstate;  // host-batch upload pipeline, owned by pipeline.hip
+struct tahoe_wstate;  // float32 walk for wide rows, owned by widef.hip
 
 namespace tahoe {
 
@@ -68,6 +69,7 @@ struct tahoe_forest {
     tahoe_qstate *q = nullptr;     // QRING: rank-quantised forest + row workspace (qring.hip)
     tahoe_sstate *sp = nullptr;    // non-null: this handle is a sparse forest (sparse.hip); the dense views are unused
     tahoe_pstate *pipe = nullptr;  // tahoe_forest_predict_host: chunk buffers, streams, events (created on first use)
+    tahoe_wstate *wf = nullptr;    // non-null: TILERING runs the wide-row float32 form (widef.hip)
     size_t device_bytes = 0;
     // Tuning knobs for experiments, read from the environment ONCE, in tahoe_forest_create (never on the predict path):
     // TAHOE_TILE_ROWS (64 / 128: rows per TILEBLOCK / TILERING tile), TAHOE_QRING_WALKERS (15 / 12 / 8 / 4).  0 = unset.
@@ -145,5 +147,11 @@ int sparse_top_waves(const tahoe_forest *f);
 bool sparse_q_available(const tahoe_forest *f);  // the walk on quantised codes (strategy QRING on a sparse handle)
 void sparse_destroy(tahoe_forest *f);
 void pipeline_destroy(tahoe_forest *f);
+// TILERING for rows too wide for a 64-row float32 tile (widef.hip)
+tahoe_status widef_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner, const std::vector<float> &h_leaf);
+int widef_rows(const tahoe_forest *f);  // rows per tile; 0 = unavailable
+tahoe_status widef_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, const float *data, size_t rows, hipStream_t stream,
+                          const float *sums_in);
+void widef_destroy(tahoe_forest *f);
 
 }  // namespace tahoe

@@ -410,8 +410,18 @@ __global__ void __launch_bounds__(16 * 64)
             }
             if (dead) break;
             asm volatile("" ::: "memory");  // the values are read after the flags
-            if (lane < RT)
-                for (int j = 0; j < nb; ++j) sum += ring_vals[((t0 + j) % RE) * RT + lane];  // tree order
+            if (lane < RT) {  // tree order; eight loads in flight, eight adds in order (one tree at a time, a load's
+                               // latency per tree, made this wave the bottleneck of a 16-row tile: 500 trees x ~100 clk)
+                int jj = 0;
+                for (; jj + 8 <= nb; jj += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = ring_vals[((t0 + jj + u) % RE) * RT + lane];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) sum += v[u];
+                }
+                for (; jj < nb; ++jj) sum += ring_vals[((t0 + jj) % RE) * RT + lane];
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane == 0) lds_flag_store(consumed, (uint32_t)(t0 + nb));
         }

@@ -79,9 +79,14 @@ def test_k2_svhn_like_wide_rows(env):
     data = ta.synth_data(R, C, seed=22, missing_prob=0.001, missing=MISSING)
     x = torch.from_numpy(data).cuda()
     forest = ta.Forest(nodes, T, D, C, missing=MISSING)
-    assert forest.get_strategy(R) == ta.STRATEGY_QRING and forest.info().qring_tile_rows in (16, 32, 64)
+    # 2 * 500 * 8 lookups per row against 3072 features: too little walking to pay a quantise pass -> the float32 wide form
+    assert forest.get_strategy(R) == ta.STRATEGY_TILERING and forest.info().ring_rows == 8
+    assert forest.info().qring_tile_rows in (16, 32, 64)  # the quantised wide form stays available
     got = forest.predict_raw(x).cpu().numpy()
     forest.check()
+    forest.set_strategy(ta.STRATEGY_QRING)
+    assert np.array_equal(bits(forest.predict_raw(x).cpu().numpy()), bits(got))  # every row, the other wide form
+    forest.set_strategy(ta.STRATEGY_AUTO)
     idx = strided(R, 50)
     want, want_leaf = oracle.predict(nodes, T, D, data[idx], MISSING, want_leaf=True, threads=8)
     assert np.array_equal(bits(got[idx]), bits(want))

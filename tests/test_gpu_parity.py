@@ -63,7 +63,7 @@ SHAPES = [
     (20, 12, 256, 2000, 0.0),   # K3 shape, small
     (9, 12, 256, 511, 0.15),
     (33, 10, 500, 129, 0.0),    # 125 KiB tile: one workgroup per CU
-    (6, 7, 3072, 200, 0.0),     # K2-like width: the row tile does not fit LDS -> DIRECT only
+    (6, 7, 3072, 200, 0.0),     # K2-like width: no 64-row float32 tile -> 8-row float32 tiles (TILERING), 16-row u16 tiles (QRING)
     (3, 14, 40, 97, 0.02),
 ]
 
@@ -195,8 +195,9 @@ def test_invalid_forests_are_rejected(env):
     with pytest.raises(ta.TahoeError) as e:
         f.set_strategy(ta.STRATEGY_ROWTILE)
     assert e.value.status == 7
-    # too wide for any float32 row tile: AUTO takes the quantised walk (16-row u16 tiles, four trees per wave)
-    assert f.get_strategy(100) == ta.STRATEGY_QRING and f.info().qring_walkers == 15
+    # too wide for a 64-row float32 tile: TILERING is the wide-row form (8-row float32 tiles, eight trees per wave), which AUTO
+    # takes for so little walking per feature value; the quantised walk (16-row u16 tiles) stays available
+    assert f.get_strategy(100) == ta.STRATEGY_TILERING and f.info().ring_rows == 8 and f.info().qring_walkers == 15
 
 
 def test_golden_fixtures(env):
@@ -733,3 +734,36 @@ def test_two_handles_on_two_streams_concurrently(env):
         assert np.array_equal(bits(outs_b[i].cpu().numpy()), bits(want_b)), i
     a.close()
     b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,D,C,R,missing_prob", [
+    (300, 8, 3072, 1003, 0.0),    # K2's shape: 8-row tiles, eight trees per wave; more trees than ring entries; ragged last tile
+    (300, 8, 3072, 1003, 0.03),   # ... with missing values and NaN: the full branch rule
+    (37, 10, 2050, 333, 0.02),    # cols not a multiple of 4 (scalar staging); levels 6..7 from the heap in global memory
+    (5, 2, 1000, 70, 0.05),       # two levels: no LDS top at all, one block per tree
+    (9, 3, 700, 64, 0.0),         # 32-row tiles, one top level
+    (66, 12, 600, 500, 0.01),     # deep trees on 32-row tiles: eight levels in LDS, two from the heap, two in the blocks
+    (129, 9, 1500, 257, 0.0),     # 16-row tiles
+])
+def test_wide_rows_float32_form(env, T, D, C, R, missing_prob):
+    """TILERING on rows too wide for a 64-row float32 tile (widef.hip): leaf indices and sums against the oracle, continued
+    sums, and the same bits as the quantised wide form and DIRECT."""
+    ta, oracle, torch = env
+    nodes = ta.synth_forest(T, D, C, seed=900 + T, leaf_prob=0.1 if D > 4 else 0.0)
+    data = ta.synth_data(R, C, seed=901 + R, missing_prob=missing_prob, missing=MISSING, nan_prob=missing_prob / 2)
+    if missing_prob:
+        data[3, :5] = [np.inf, -np.inf, -0.0, MISSING + 5e-7, MISSING - 2e-6]
+    f = ta.Forest(nodes, T, D, C, missing=MISSING)
+    assert f.info().ring_rows in (8, 16, 32)
+    f.close()
+    want, _ = run_case(env, nodes, T, D, C, data, strategies=[ta.STRATEGY_TILERING, ta.STRATEGY_QRING, ta.STRATEGY_DIRECT, ta.STRATEGY_AUTO])
+    f = ta.Forest(nodes, T, D, C, missing=MISSING)
+    f.set_strategy(ta.STRATEGY_TILERING)
+    x = torch.from_numpy(data).cuda()
+    start = np.linspace(-2.0, 2.0, R).astype(np.float32)
+    acc = f.predict_accumulate(x, torch.from_numpy(start.copy()).cuda())
+    f.check()
+    cont = oracle.predict_continue(nodes, T, D, data, MISSING, start)
+    assert np.array_equal(bits(acc.cpu().numpy()), bits(cont))
+    f.close()

@@ -1,4 +1,4 @@
-"""Soak: many back-to-back predicts of the ring kernels (K3 QRING, K2 wide form, K5 sparse: quantised and float32), then tahoe_forest_check
+"""Soak: many back-to-back predicts of the ring kernels (K3 QRING, K2 wide forms, K5 sparse: quantised and float32), then tahoe_forest_check
 (a bounded LDS wait that ever timed out raises) and a bit-for-bit comparison of the last result with the first."""
 import os, sys, time
 import numpy as np, torch
@@ -36,5 +36,7 @@ f.close()
 del x
 x = torch.from_numpy(ta.synth_data(100_000, 3072, seed=22)).cuda()
 f = ta.Forest(ta.synth_forest(500, 8, 3072, seed=21), 500, 8, 3072, missing=-999.0)
-soak("K2 wide", f, x, 300)
+soak("K2 wide, float32 ring", f, x, 300)
+f.set_strategy(ta.STRATEGY_QRING)
+soak("K2 wide, quantised ring", f, x, 200)
 f.close()
