@@ -1,0 +1,56 @@
+"""Randomised differential test: random dense and sparse forests / batches, every available strategy against the CPU oracle
+(leaf indices and float32 sums, bit for bit), for a given number of seconds.  python tests/fuzz_gpu.py [seconds] [seed]  (test infrastructure: it uses the CPU oracle as the checker)"""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tahoe_amd as ta
+from oracle import oracle
+
+MISSING = -999.0
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bits = lambda a: np.ascontiguousarray(a).view(np.uint32)
+t_end = time.time() + budget
+cases = checks = 0
+while time.time() < t_end:
+    sparse = rng.random() < 0.35
+    C = int(rng.choice([1, 2, 3, 7, 18, 32, 64, 100, 255, 256, 257, 500, 513, 600, 1000, 1536, 2050, 3072]))
+    R = int(rng.choice([1, 5, 63, 64, 65, 127, 129, 191, 193, 384, 500, 1000, 2049, 5000]))
+    mp = float(rng.choice([0.0, 0.0, 0.02, 0.2]))
+    data = ta.synth_data(R, C, seed=int(rng.integers(1 << 30)), missing_prob=mp, missing=MISSING, nan_prob=mp / 2)
+    x = torch.from_numpy(data).cuda()
+    if sparse:
+        T = int(rng.choice([1, 3, 17, 40, 150, 400]))
+        dmin = int(rng.integers(0, 6)); dmax = dmin + int(rng.integers(0, 14))
+        sn, tr = ta.capi.synth_sparse_forest(T, C, dmin, dmax, float(rng.choice([0.0, 0.1, 0.35])), 65535, int(rng.integers(1 << 30)))
+        want, want_leaf = oracle.sparse_predict(sn, tr, data, MISSING, want_leaf=True, threads=8)
+        f = ta.capi.SparseForest(sn, tr, C, missing=MISSING)
+        strategies = [ta.STRATEGY_AUTO, ta.STRATEGY_DIRECT, ta.STRATEGY_ROWTILE, ta.STRATEGY_TILEBLOCK, ta.STRATEGY_QRING]
+        desc = f"sparse T={T} depth={dmin}..{dmax} C={C} R={R} missing={mp}"
+    else:
+        T = int(rng.choice([1, 2, 5, 16, 33, 100, 300]))
+        D = int(rng.choice([0, 1, 2, 3, 5, 8, 10, 12])) if C <= 600 else int(rng.choice([2, 3, 6, 8, 10]))
+        nodes = ta.synth_forest(T, D, C, seed=int(rng.integers(1 << 30)), leaf_prob=float(rng.choice([0.0, 0.1, 0.3])))
+        want, want_leaf = oracle.predict(nodes, T, D, data, MISSING, want_leaf=True, threads=8)
+        f = ta.Forest(nodes, T, D, C, missing=MISSING)
+        strategies = [ta.STRATEGY_AUTO, ta.STRATEGY_DIRECT, ta.STRATEGY_ROWTILE, ta.STRATEGY_TILEBLOCK, ta.STRATEGY_TILERING, ta.STRATEGY_QRING]
+        desc = f"dense T={T} D={D} C={C} R={R} missing={mp}"
+    for s in strategies:
+        try:
+            f.set_strategy(s)
+        except ta.TahoeError:
+            continue
+        leaf, sums = f.predict_leaf_idx(x)
+        raw = f.predict_raw(x)
+        f.check()
+        ok = (np.array_equal(bits(leaf.cpu().numpy()), want_leaf) and np.array_equal(bits(sums.cpu().numpy()), bits(want))
+              and np.array_equal(bits(raw.cpu().numpy()), bits(want)))
+        checks += 1
+        if not ok:
+            print("MISMATCH", desc, "strategy", s, ta.STRATEGY_NAMES[f.get_strategy(R)], flush=True)
+            sys.exit(1)
+    f.close()
+    cases += 1
+    if cases % 25 == 0:
+        print(f"{cases} cases, {checks} strategy runs, last: {desc}", flush=True)
+print(f"fuzz ok: {cases} cases, {checks} strategy runs, all bit-exact")
