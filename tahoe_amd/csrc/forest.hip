@@ -720,7 +720,9 @@ static int resolve_strategy(const tahoe_forest *f, size_t rows)
     // when there is little walking per feature value (trees x depth < 6.5 x cols).  On ten shapes it was not fitted
     // on (--holdout) it picks the fastest strategy on 8 and stays within 1.16x on the other two.
     const bool shallow = f->depth <= 4 && rowtile_fits(f);
-    const bool little_work = 2LL * f->p.num_trees * f->depth < 13LL * f->p.num_cols &&
+    // (wide rows whose quantised form walks three trees per lane: that form is ~1.25 x faster, the float32 form pays off later)
+    const long long per_col = qwide_chains(f) == 3 ? 10 : 13;
+    const bool little_work = 2LL * f->p.num_trees * f->depth < per_col * f->p.num_cols &&
                              (tilering_rows(f) > 0 || widef_rows(f) > 0 || tileblock_rows(f) > 0 || rowtile_fits(f));
     if (shallow) return TAHOE_STRATEGY_ROWTILE;
     if (qring_walkers(f) > 0 && !little_work) return TAHOE_STRATEGY_QRING;

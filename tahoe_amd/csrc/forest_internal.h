@@ -135,6 +135,7 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
                           hipStream_t stream, hipEvent_t mid_event, const float *sums_in = nullptr);
 tahoe_status qring_reserve(tahoe_forest *f, size_t rows);
 int qwide_rows(const tahoe_forest *f);   // rows per tile of the wide-row form; 0 = not used
+int qwide_chains(const tahoe_forest *f); // ... and the trees a lane walks at once (1 or 3)
 bool qring_lds_tile(const tahoe_forest *f);
 bool qring_regions(const tahoe_forest *f);  // region form: tiles of 192 (or 128) rows as 64-row regions
 int qring_groups(const tahoe_forest *f);  // tree groups with separate quantisation (1 for most forests)

@@ -352,8 +352,12 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
 // thrashes: 32 workgroups per XCD x 768 KiB against a 4 MiB L2.)  Tiles are xq[tile][fid][RT] u16, rows in order.
 // Tops: the first 2^LW heap entries of each tree's `top` array, LW = min(top_levels, log2(1024 / TPW)): a 4 KiB slot
 // per wave; levels LW .. De-3 come from the quantised heap in global memory (qinner).
+// KG = 3 (small tops, e.g. K2's depth-8 trees: 256 B each): a walker wave holds three such groups of trees in its slot and
+// every lane walks three trees at once, chain k = tree j + k * TPW of the 3 * TPW consecutive trees of the iteration -- three
+// independent dependent-read chains per wave instead of one, with a ring of 16 KiB for the larger number of trees in flight.
 constexpr int kWideRingBytes = 8192;
-template <int RT, bool WRITE_LEAF>
+constexpr int kWideRingBytesK = 16384;  // ring of the KG = 3 form
+template <int RT, bool WRITE_LEAF, int KG = 1, int RB = kWideRingBytes>
 __global__ void __launch_bounds__(16 * 64)
     qwide_kernel(const uint16_t *__restrict__ xq, const uint32_t *__restrict__ top, const uint4 *__restrict__ blocks,
                  const uint32_t *__restrict__ qinner, const uint32_t *__restrict__ leaf_orig, float *__restrict__ sums,
@@ -363,14 +367,15 @@ __global__ void __launch_bounds__(16 * 64)
 {
     constexpr int NWALK = 15;
     constexpr int NT = (NWALK + 1) * 64;
-    constexpr int TPW = 64 / RT;                       // trees a walker wave walks at once
-    constexpr int RE = kWideRingBytes / (RT * 4);      // ring entries (trees): >= two rounds of NWALK * TPW
+    constexpr int TPW = 64 / RT;                       // trees a walker wave walks at once, per chain
+    constexpr int TPG = TPW * KG;                      // ... in all: the consecutive trees of one walker iteration
+    constexpr int RE = RB / (RT * 4);                  // ring entries (trees)
 #ifndef TAHOE_WIDE_BATCH
 #define TAHOE_WIDE_BATCH 64  // K2 (four trees per wave): 64 -> 1.07 ms, 16 -> 1.16, 8 -> 1.44
 #endif
     constexpr int NBATCH = RE / 2 < TAHOE_WIDE_BATCH ? RE / 2 : TAHOE_WIDE_BATCH;  // trees the consumer takes per poll (<= 64)
     constexpr int CSHIFT = RT == 64 ? 7 : RT == 32 ? 6 : 5;  // log2 of a feature column's bytes
-    static_assert(NBATCH <= 64 && RE >= 2 * NWALK * TPW, "ring too small");
+    static_assert(NBATCH <= 64 && RE >= (KG == 1 ? 2 : 1) * NWALK * TPG, "ring too small");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -434,15 +439,14 @@ __global__ void __launch_bounds__(16 * 64)
     const int j = lane / RT, r = lane % RT;           // tree slot, row of the tile
     // lw (<= min(top_levels, LWMAX), chosen at create so that tile + slots fit): levels served from the LDS slot
     const int cpt = max(1, (1 << lw) >> 2);           // 16-byte chunks per staged top (top_stride >= 4 entries)
-    unsigned char *wslot = slots + (size_t)wave * slot_bytes;
-    const uint32_t *slot = reinterpret_cast<const uint32_t *>(wslot + (size_t)j * cpt * 16);
-    const int n_groups = (num_trees + TPW - 1) / TPW;
+    unsigned char *wslot = slots + (size_t)wave * slot_bytes;  // TPG tops: tree jj of the iteration at jj * cpt * 16
+    const int n_groups = (num_trees + TPG - 1) / TPG;
     uint4 pf0 = {}, pf1 = {}, pf2 = {}, pf3 = {};
-    // chunk c of the wave's slot = chunk (c % cpt) of tree g * TPW + c / cpt (clamped: in bounds, branch-free)
+    // chunk c of the wave's slot = chunk (c % cpt) of tree g * TPG + c / cpt (clamped: in bounds, branch-free); TPG * cpt <= 256
     auto prefetch_tops = [&](int g) {
         auto ld = [&](int c) {
-            c = min(c, TPW * cpt - 1);
-            const int t = min(g * TPW + c / cpt, num_trees - 1);
+            c = min(c, TPG * cpt - 1);
+            const int t = min(g * TPG + c / cpt, num_trees - 1);
             return reinterpret_cast<const uint4 *>(top + (size_t)t * top_stride)[c % cpt];
         };
         pf0 = ld(0 * 64 + lane);
@@ -450,9 +454,9 @@ __global__ void __launch_bounds__(16 * 64)
         pf2 = ld(2 * 64 + lane);
         pf3 = ld(3 * 64 + lane);
     };
-    auto commit_tops = [&]() {  // TPW * cpt <= 256 chunks; clamped lanes rewrite the last chunk with its own value
+    auto commit_tops = [&]() {  // clamped lanes rewrite the last chunk with its own value
         uint4 *s = reinterpret_cast<uint4 *>(wslot);
-        const int last = TPW * cpt - 1;
+        const int last = TPG * cpt - 1;
         s[min(0 * 64 + lane, last)] = pf0;
         s[min(1 * 64 + lane, last)] = pf1;
         s[min(2 * 64 + lane, last)] = pf2;
@@ -472,20 +476,27 @@ __global__ void __launch_bounds__(16 * 64)
         const uint32_t n_blocks = 1u << (depth - 2);
         const uint32_t first_block_node = n_blocks - 1;
         const size_t row = row0 + r;
-        auto finish = [&](int g, const uint4 &na, const uint4 &nb, uint32_t bs) {
-            const int t = g * TPW + j;
-            const bool c0 = q_go_right<MS, false>(q_xread<true, false, CSHIFT>(nullptr, na.x, pos), na.x);
-            const uint32_t n1 = c0 ? na.z : na.y;
-            const bool c1 = q_go_right<MS, false>(q_xread<true, false, CSHIFT>(nullptr, n1, pos), n1);
-            const uint32_t lo = c0 ? nb.z : nb.x, hi = c0 ? nb.w : nb.y;
-            const float v = __uint_as_float(c1 ? hi : lo);
-            if (WRITE_LEAF) {
-                if (t < num_trees && row < rows)
-                    leaf_out[row * (size_t)total_trees + tree_base + t] =
-                        leaf_orig[(size_t)t * ((size_t)n_blocks * 4) + (size_t)bs * 4 + 2 * (c0 ? 1 : 0) + (c1 ? 1 : 0)];
+        const uint32_t *slot[KG];  // chain k walks tree k * TPW + j of the iteration
+#pragma unroll
+        for (int k = 0; k < KG; ++k) slot[k] = reinterpret_cast<const uint32_t *>(wslot + (size_t)(k * TPW + j) * cpt * 16);
+        auto finish = [&](int g, const uint4 (&na)[KG], const uint4 (&nb)[KG], const uint32_t (&bs)[KG]) {
+            float v[KG];
+#pragma unroll
+            for (int k = 0; k < KG; ++k) {
+                const int t = g * TPG + k * TPW + j;
+                const bool c0 = q_go_right<MS, false>(q_xread<true, false, CSHIFT>(nullptr, na[k].x, pos), na[k].x);
+                const uint32_t n1 = c0 ? na[k].z : na[k].y;
+                const bool c1 = q_go_right<MS, false>(q_xread<true, false, CSHIFT>(nullptr, n1, pos), n1);
+                const uint32_t lo = c0 ? nb[k].z : nb[k].x, hi = c0 ? nb[k].w : nb[k].y;
+                v[k] = __uint_as_float(c1 ? hi : lo);
+                if (WRITE_LEAF) {
+                    if (t < num_trees && row < rows)
+                        leaf_out[row * (size_t)total_trees + tree_base + t] =
+                            leaf_orig[(size_t)t * ((size_t)n_blocks * 4) + (size_t)bs[k] * 4 + 2 * (c0 ? 1 : 0) + (c1 ? 1 : 0)];
+                }
             }
-            const int t_last = min(g * TPW + TPW - 1, num_trees - 1);
-            if (t_last >= RE) {  // the group's ring entries still in use?
+            const int t_last = min(g * TPG + TPG - 1, num_trees - 1);
+            if (t_last >= RE) {  // the iteration's ring entries still in use?
                 int spins = 0;
                 while (lds_flag_load(consumed) < (uint32_t)(t_last - RE + 1)) {
                     if (++spins > kQSpinLimit) {
@@ -495,46 +506,79 @@ __global__ void __launch_bounds__(16 * 64)
                     __builtin_amdgcn_s_sleep(1);
                 }
             }
-            if (t < num_trees) ring_vals[(t % RE) * RT + r] = v;
+#pragma unroll
+            for (int k = 0; k < KG; ++k) {
+                const int t = g * TPG + k * TPW + j;
+                if (t < num_trees) ring_vals[(t % RE) * RT + r] = v[k];
+            }
             asm volatile("" ::: "memory");  // values before the flags: a wave's LDS operations are performed in issue order
-            if (r == 0 && t < num_trees) lds_flag_store(&ring_ready[t % RE], (uint32_t)(t + 1));
+#pragma unroll
+            for (int k = 0; k < KG; ++k) {
+                const int t = g * TPG + k * TPW + j;
+                if (r == 0 && t < num_trees) lds_flag_store(&ring_ready[t % RE], (uint32_t)(t + 1));
+            }
         };
-        int g_p = -1;  // group whose bottom blocks are in flight
-        uint4 na_p = {}, nb_p = {};
-        uint32_t bsel_p = 0;
+        int g_p = -1;  // iteration whose bottom blocks are in flight
+        uint4 na_p[KG] = {}, nb_p[KG] = {};
+        uint32_t bsel_p[KG] = {};
         for (int g = wave; g < n_groups && !dead; g += NWALK) {
             const bool more = g + NWALK < n_groups;
             if (more) prefetch_tops(g + NWALK);
-            const int t = min(g * TPW + j, num_trees - 1);  // lanes of a missing tree repeat the last one, unused
-            uint32_t i = 1;
+            int t[KG];  // lanes of a missing tree repeat the last one, unused
+            uint32_t i[KG];
+#pragma unroll
+            for (int k = 0; k < KG; ++k) {
+                t[k] = min(g * TPG + k * TPW + j, num_trees - 1);
+                i[k] = 1;
+            }
             if (lw > 0) {
-                uint32_t node = slot[1];
+                uint32_t node[KG];
+#pragma unroll
+                for (int k = 0; k < KG; ++k) node[k] = slot[k][1];
                 for (int l = 0; l < lw - 1; ++l) {
-                    const uint32_t xc = q_xread<true, false, CSHIFT>(nullptr, node, pos);
-                    const uint2 pr = *reinterpret_cast<const uint2 *>(&slot[2 * i]);  // children 2i, 2i+1
-                    const uint64_t cm = q_right_mask<MS, false>(xc, node);
-                    i = q_descend(i, cm);
-                    node = __builtin_amdgcn_inverse_ballot_w64(cm) ? pr.y : pr.x;
+                    uint32_t xc[KG];
+                    uint2 pr[KG];
+#pragma unroll
+                    for (int k = 0; k < KG; ++k) {
+                        xc[k] = q_xread<true, false, CSHIFT>(nullptr, node[k], pos);
+                        pr[k] = *reinterpret_cast<const uint2 *>(&slot[k][2 * i[k]]);  // children 2i, 2i+1
+                    }
+#pragma unroll
+                    for (int k = 0; k < KG; ++k) {
+                        const uint64_t cm = q_right_mask<MS, false>(xc[k], node[k]);
+                        i[k] = q_descend(i[k], cm);
+                        node[k] = __builtin_amdgcn_inverse_ballot_w64(cm) ? pr[k].y : pr[k].x;
+                    }
                 }
-                const uint32_t xc = q_xread<true, false, CSHIFT>(nullptr, node, pos);
-                i = q_descend(i, q_right_mask<MS, false>(xc, node));
-            }
-            uint32_t idx = i - 1;  // 0-based heap index on level lw
-            if (lw < depth - 2) {  // the levels between the slot and the bottom blocks: quantised heap in global memory
-                const uint32_t *tree = qinner + (size_t)t * n_inner;
-                for (int l = lw; l < depth - 2; ++l) {
-                    const uint32_t n = tree[idx];
-                    const uint32_t xc = q_xread<true, false, CSHIFT>(nullptr, n, pos);
-                    idx = 2u * idx + 1u + (q_go_right<MS, false>(xc, n) ? 1u : 0u);
+#pragma unroll
+                for (int k = 0; k < KG; ++k) {
+                    const uint32_t xc = q_xread<true, false, CSHIFT>(nullptr, node[k], pos);
+                    i[k] = q_descend(i[k], q_right_mask<MS, false>(xc, node[k]));
                 }
             }
-            const uint32_t bsel = idx - first_block_node;
+            uint32_t bsel[KG];
+#pragma unroll
+            for (int k = 0; k < KG; ++k) {
+                uint32_t idx = i[k] - 1;  // 0-based heap index on level lw
+                if (lw < depth - 2) {  // the levels between the slot and the bottom blocks: quantised heap in global memory
+                    const uint32_t *tree = qinner + (size_t)t[k] * n_inner;
+                    for (int l = lw; l < depth - 2; ++l) {
+                        const uint32_t n = tree[idx];
+                        const uint32_t xc = q_xread<true, false, CSHIFT>(nullptr, n, pos);
+                        idx = 2u * idx + 1u + (q_go_right<MS, false>(xc, n) ? 1u : 0u);
+                    }
+                }
+                bsel[k] = idx - first_block_node;
+            }
             if (g_p >= 0) finish(g_p, na_p, nb_p, bsel_p);
             g_p = g;
-            const uint4 *bp = blocks + ((size_t)t * n_blocks + bsel) * 2;
-            na_p = bp[0];
-            nb_p = bp[1];
-            bsel_p = bsel;
+#pragma unroll
+            for (int k = 0; k < KG; ++k) {
+                const uint4 *bp = blocks + ((size_t)t[k] * n_blocks + bsel[k]) * 2;
+                na_p[k] = bp[0];
+                nb_p[k] = bp[1];
+                bsel_p[k] = bsel[k];
+            }
             if (more) commit_tops();
         }
         if (g_p >= 0 && !dead) finish(g_p, na_p, nb_p, bsel_p);
@@ -579,13 +623,23 @@ bool qring_lds_tile(const tahoe_forest *f) { return qring_lds_for(f, 4) <= f->ld
 // Wide form, `rt` rows per tile: a wave's slot holds TPW = 64 / rt tops of 2^lw u32, at most 4 KiB
 static int qwide_lw_max(int top_levels, int rt) { return std::min(top_levels, rt == 64 ? 10 : rt == 32 ? 9 : 8); }
 static long long qwide_slot_bytes(int lw, int rt) { return (64 / rt) * (long long)std::max(1, (1 << lw) >> 2) * 16; }
-static long long qwide_lds_for(const tahoe_forest *f, int rt, int lw)
+static long long qwide_lds_for(const tahoe_forest *f, int rt, int lw, int kg = 1)
 {
-    return (long long)f->p.num_cols * rt * 2 + 15LL * qwide_slot_bytes(lw, rt) + kWideRingBytes +
-           (kWideRingBytes / (rt * 4) + 1) * 4LL;
+    const long long ring = kg > 1 ? kWideRingBytesK : kWideRingBytes;
+    return (long long)f->p.num_cols * rt * 2 + 15LL * kg * qwide_slot_bytes(lw, rt) + ring + (ring / (rt * 4) + 1) * 4LL;
+}
+// tree groups per walker (chains per lane) of the wide form: 3 when three groups of tops fill at most 256 16-byte chunks and
+// fit LDS beside the tile and the larger ring, else 1
+static int qwide_kg(const tahoe_forest *f, int rt, int lw)
+{
+    if (const char *e = getenv("TAHOE_QRING_WIDE_CHAINS"))  // experiments: 1 keeps one group per walker
+        if (atoi(e) == 1) return 1;
+    const long long chunks = 3LL * qwide_slot_bytes(lw, rt) / 16;
+    return (chunks <= 256 && qwide_lds_for(f, rt, lw, 3) <= f->lds_limit) ? 3 : 1;
 }
 // rows per tile of the wide-row form (qwide_kernel); 0 = not used (the 128-row tile fits, or not even 16 rows do)
 int qwide_rows(const tahoe_forest *f) { return f->q ? f->q->wide_rt : 0; }
+int qwide_chains(const tahoe_forest *f) { return f->q && f->q->wide_rt ? f->q->wide_kg : 0; }  // trees a lane walks at once; 0 = form not used
 // Largest tile first; within a tile size up to three top levels may move from the LDS slots to the global heap to
 // make room for the tile.
 static void qwide_pick(const tahoe_forest *f, int *rt_out, int *lw_out)
@@ -752,6 +806,7 @@ tahoe_status qring_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner,
     q->top_levels = f->top_levels;
     q->have_mid = f->depth - 2 > q->top_levels;
     qwide_pick(f, &q->wide_rt, &q->wide_lw);
+    q->wide_kg = q->wide_rt ? qwide_kg(f, q->wide_rt, q->wide_lw) : 1;
     if (q->wide_rt) q->have_mid = q->have_mid || f->depth - 2 > q->wide_lw;  // smaller tops in LDS
     q->top_stride = (int)std::max<size_t>((size_t)1 << q->top_levels, 4);  // >= 16 bytes per tree
     {
@@ -823,7 +878,10 @@ tahoe_status qring_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner,
     if ((e = allow_max_lds(reinterpret_cast<const void *>(&qring_kernel<kGxWalkers, true, false>), f->lds_limit)) != hipSuccess)
         return bad("attr(gx)");
     for (const void *k : {(const void *)&qwide_kernel<64, false>, (const void *)&qwide_kernel<64, true>, (const void *)&qwide_kernel<32, false>,
-                          (const void *)&qwide_kernel<32, true>, (const void *)&qwide_kernel<16, false>, (const void *)&qwide_kernel<16, true>})
+                          (const void *)&qwide_kernel<32, true>, (const void *)&qwide_kernel<16, false>, (const void *)&qwide_kernel<16, true>,
+                          (const void *)&qwide_kernel<64, false, 3, kWideRingBytesK>, (const void *)&qwide_kernel<64, true, 3, kWideRingBytesK>,
+                          (const void *)&qwide_kernel<32, false, 3, kWideRingBytesK>, (const void *)&qwide_kernel<32, true, 3, kWideRingBytesK>,
+                          (const void *)&qwide_kernel<16, false, 3, kWideRingBytesK>, (const void *)&qwide_kernel<16, true, 3, kWideRingBytesK>})
         if ((e = allow_max_lds(k, f->lds_limit)) != hipSuccess) return bad("attr(qwide)");
     if ((e = quantize_allow_lds(f)) != hipSuccess) return bad("attr(quantise kernels)");
     return TAHOE_OK;
@@ -953,24 +1011,33 @@ static void q_launch(tahoe_forest *f, const tahoe_qgroup &g, float *sums, const 
                            sums_in, sums, rows);
 }
 
+template <int RT, int KG, int RB>
+static void qwide_launch_form(tahoe_forest *f, const tahoe_qgroup &g, float *sums, const float *sums_in, uint32_t *leaf_out,
+                              size_t rows, hipStream_t stream, int cshift)
+{
+    tahoe_qstate *q = f->q;
+    const unsigned grid = (unsigned)((rows + RT - 1) / RT);
+    const int lds = (int)qwide_lds_for(f, RT, q->wide_lw, KG);
+    const int slot_bytes = KG * (int)qwide_slot_bytes(q->wide_lw, RT);
+    const uint32_t *leaf_orig = f->leaf_orig + (size_t)g.tree_lo * f->n_leaf;
+    if (leaf_out)
+        hipLaunchKernelGGL((qwide_kernel<RT, true, KG, RB>), dim3(grid), dim3(16 * 64), lds, stream, q->xq, g.top, g.blocks, g.qinner,
+                           leaf_orig, sums, leaf_out, rows, f->p.num_cols, g.num_trees, f->depth, q->top_levels, q->top_stride,
+                           q->chunk_flags, f->error_flag, sums_in, g.tree_lo, f->p.num_trees, slot_bytes, q->wide_lw, cshift);
+    else
+        hipLaunchKernelGGL((qwide_kernel<RT, false, KG, RB>), dim3(grid), dim3(16 * 64), lds, stream, q->xq, g.top, g.blocks, g.qinner,
+                           leaf_orig, sums, leaf_out, rows, f->p.num_cols, g.num_trees, f->depth, q->top_levels, q->top_stride,
+                           q->chunk_flags, f->error_flag, sums_in, g.tree_lo, f->p.num_trees, slot_bytes, q->wide_lw, cshift);
+}
+
 template <int RT>
 static void qwide_launch(tahoe_forest *f, const tahoe_qgroup &g, float *sums, const float *sums_in, uint32_t *leaf_out,
                          size_t rows, hipStream_t stream, int cshift)
 {
-    tahoe_qstate *q = f->q;
-    const unsigned grid = (unsigned)((rows + RT - 1) / RT);
-    const int lds = (int)qwide_lds_for(f, RT, q->wide_lw);
-    const uint32_t *leaf_orig = f->leaf_orig + (size_t)g.tree_lo * f->n_leaf;
-    if (leaf_out)
-        hipLaunchKernelGGL((qwide_kernel<RT, true>), dim3(grid), dim3(16 * 64), lds, stream, q->xq, g.top, g.blocks, g.qinner,
-                           leaf_orig, sums, leaf_out, rows, f->p.num_cols, g.num_trees, f->depth, q->top_levels, q->top_stride,
-                           q->chunk_flags, f->error_flag, sums_in, g.tree_lo, f->p.num_trees,
-                           (int)qwide_slot_bytes(q->wide_lw, RT), q->wide_lw, cshift);
+    if (f->q->wide_kg == 3)
+        qwide_launch_form<RT, 3, kWideRingBytesK>(f, g, sums, sums_in, leaf_out, rows, stream, cshift);
     else
-        hipLaunchKernelGGL((qwide_kernel<RT, false>), dim3(grid), dim3(16 * 64), lds, stream, q->xq, g.top, g.blocks, g.qinner,
-                           leaf_orig, sums, leaf_out, rows, f->p.num_cols, g.num_trees, f->depth, q->top_levels, q->top_stride,
-                           q->chunk_flags, f->error_flag, sums_in, g.tree_lo, f->p.num_trees,
-                           (int)qwide_slot_bytes(q->wide_lw, RT), q->wide_lw, cshift);
+        qwide_launch_form<RT, 1, kWideRingBytes>(f, g, sums, sums_in, leaf_out, rows, stream, cshift);
 }
 
 tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, const float *data, size_t rows,

@@ -45,6 +45,7 @@ struct tahoe_qstate {
     bool sparse = false;          // the handle is a sparse forest: tables, workspace and region tiles only (sparse.hip walks)
     int wide_rt = 0;              // rows per tile of the wide-row form (qwide_kernel), fixed at create; 0 = not used
     int wide_lw = 0;              // ... and the top levels its LDS slots hold
+    int wide_kg = 1;              // ... and the groups of trees a walker wave holds (chains per lane): 1 or 3
     std::vector<tahoe_qgroup> groups;
     uint16_t *xq = nullptr;       // workspace: quantised tiles (re-used by every group)
     size_t xq_rows = 0;           // rows the workspace holds
