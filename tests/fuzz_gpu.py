@@ -9,6 +9,7 @@ from oracle import oracle
 MISSING = -999.0
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+BIG = len(sys.argv) > 3 and sys.argv[3] == "big"  # batches of several waves of tiles (mixed tile plans), hundreds of trees
 bits = lambda a: np.ascontiguousarray(a).view(np.uint32)
 t_end = time.time() + budget
 cases = checks = 0
@@ -16,11 +17,14 @@ while time.time() < t_end:
     sparse = rng.random() < 0.35
     C = int(rng.choice([1, 2, 3, 7, 18, 32, 64, 100, 255, 256, 257, 500, 513, 600, 1000, 1536, 2050, 3072]))
     R = int(rng.choice([1, 5, 63, 64, 65, 127, 129, 191, 193, 384, 500, 1000, 2049, 5000]))
+    if BIG:
+        C = int(rng.choice([18, 64, 255, 256, 600, 1536, 3072]))
+        R = int(rng.choice([20_000, 49_153, 50_000, 66_000, 98_305, 120_000])) if C <= 600 else int(rng.choice([3_000, 9_000, 20_000]))
     mp = float(rng.choice([0.0, 0.0, 0.02, 0.2]))
     data = ta.synth_data(R, C, seed=int(rng.integers(1 << 30)), missing_prob=mp, missing=MISSING, nan_prob=mp / 2)
     x = torch.from_numpy(data).cuda()
     if sparse:
-        T = int(rng.choice([1, 3, 17, 40, 150, 400]))
+        T = int(rng.choice([1, 3, 17, 40, 150, 400])) if not BIG else int(rng.choice([150, 400, 900]))
         dmin = int(rng.integers(0, 6)); dmax = dmin + int(rng.integers(0, 14))
         sn, tr = ta.capi.synth_sparse_forest(T, C, dmin, dmax, float(rng.choice([0.0, 0.1, 0.35])), 65535, int(rng.integers(1 << 30)))
         want, want_leaf = oracle.sparse_predict(sn, tr, data, MISSING, want_leaf=True, threads=8)
@@ -28,7 +32,7 @@ while time.time() < t_end:
         strategies = [ta.STRATEGY_AUTO, ta.STRATEGY_DIRECT, ta.STRATEGY_ROWTILE, ta.STRATEGY_TILEBLOCK, ta.STRATEGY_QRING]
         desc = f"sparse T={T} depth={dmin}..{dmax} C={C} R={R} missing={mp}"
     else:
-        T = int(rng.choice([1, 2, 5, 16, 33, 100, 300]))
+        T = int(rng.choice([1, 2, 5, 16, 33, 100, 300])) if not BIG else int(rng.choice([100, 300, 700]))
         D = int(rng.choice([0, 1, 2, 3, 5, 8, 10, 12])) if C <= 600 else int(rng.choice([2, 3, 6, 8, 10]))
         nodes = ta.synth_forest(T, D, C, seed=int(rng.integers(1 << 30)), leaf_prob=float(rng.choice([0.0, 0.1, 0.3])))
         want, want_leaf = oracle.predict(nodes, T, D, data, MISSING, want_leaf=True, threads=8)
@@ -51,6 +55,6 @@ while time.time() < t_end:
             sys.exit(1)
     f.close()
     cases += 1
-    if cases % 25 == 0:
+    if cases % (1 if BIG else 25) == 0:
         print(f"{cases} cases, {checks} strategy runs, last: {desc}", flush=True)
 print(f"fuzz ok: {cases} cases, {checks} strategy runs, all bit-exact")
