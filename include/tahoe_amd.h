@@ -245,12 +245,16 @@ typedef struct {
     int qring_lds_bytes;     /* dynamic LDS of the QRING kernel */
     int qring_groups;        /* tree groups quantised separately (forests with > 32767 thresholds per feature) */
     int is_sparse;           /* 1: handle made by tahoe_sparse_forest_create (only the generic fields are set) */
-    int ring_rows;           /* rows per TILERING tile: 64, 128, or 0 = strategy unavailable */
-    int tilering_lds_bytes;  /* dynamic LDS of the TILERING kernel */
+    int ring_rows;           /* rows per TILERING tile: 64 or 128; 32 / 16 / 8 for the wide-row float32 form (num_cols > 512);
+                              * 0 = strategy unavailable */
+    int tilering_lds_bytes;  /* dynamic LDS of the TILERING kernel the launch takes (of the wide-row form where that runs) */
     int qring_tile_rows;     /* rows per quantised tile in LDS: 128, or 64 / 32 / 16 for wide rows (several trees per
                               * wave); 0 = features read from the quantised tile in L2, or QRING unavailable */
     int relayout;            /* 1: created with TAHOE_CREATE_PROB_RELAYOUT */
     size_t relayout_swaps;   /* internal nodes whose subtrees changed places */
+    int stream_slots;        /* > 0: the wide-row float32 form runs as the row-streaming kernel (TAHOE_WSTREAM=1 at create):
+                              * LDS row slots of the ring the rows stream through */
+    int stream_levels;       /* ... and the top levels of ALL trees it keeps resident in LDS */
 } tahoe_forest_info;
 tahoe_status tahoe_forest_get_info(const tahoe_forest *f, tahoe_forest_info *info);
 

@@ -91,6 +91,8 @@ class ForestInfo(C.Structure):
         ("qring_tile_rows", C.c_int),
         ("relayout", C.c_int),
         ("relayout_swaps", C.c_size_t),
+        ("stream_slots", C.c_int),
+        ("stream_levels", C.c_int),
     ]
 
 

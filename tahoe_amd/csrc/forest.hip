@@ -52,7 +52,7 @@ template <bool WRITE_LEAF>
 __global__ void __launch_bounds__(kBlock) direct_kernel(const InnerNode *__restrict__ inner,
                                                         const float *__restrict__ leaf_val,
                                                         const uint32_t *__restrict__ leaf_orig,
-                                                        const float *__restrict__ data, float *__restrict__ sums,
+                                                        const float *__restrict__ data, float *sums,
                                                         uint32_t *__restrict__ leaf_out, const float *sums_in, size_t rows, int cols,
                                                         int num_trees, int depth, float missing)
 {
@@ -89,7 +89,7 @@ template <bool WRITE_LEAF>
 __global__ void __launch_bounds__(kBlock) rowtile_kernel(const InnerNode *__restrict__ inner,
                                                          const float *__restrict__ leaf_val,
                                                          const uint32_t *__restrict__ leaf_orig,
-                                                         const float *__restrict__ data, float *__restrict__ sums,
+                                                         const float *__restrict__ data, float *sums,
                                                          uint32_t *__restrict__ leaf_out, const float *sums_in, size_t rows, int cols,
                                                          int num_trees, int depth, int lds_levels, float missing,
                                                          int vec4_ok)
@@ -211,7 +211,7 @@ template <int ROWS, bool WRITE_LEAF>
 __global__ void __launch_bounds__(kSlots *ROWS)
     tileblock_kernel(const unsigned char *__restrict__ top, const uint4 *__restrict__ blocks,
                      const InnerNode *__restrict__ inner, const uint32_t *__restrict__ leaf_orig,
-                     const float *__restrict__ data, float *__restrict__ sums, uint32_t *__restrict__ leaf_out,
+                     const float *__restrict__ data, float *sums, uint32_t *__restrict__ leaf_out,
                      const float *sums_in, size_t rows, int cols, int num_trees, int depth, int top_levels, int top_stride, float missing,
                      int vec4_ok)
 {
@@ -401,7 +401,7 @@ template <int ROWS, int NWALK, bool WRITE_LEAF>
 __global__ void __launch_bounds__((NWALK + 1) * 64)
     tilering_kernel(const unsigned char *__restrict__ top, const uint4 *__restrict__ blocks,
                     const InnerNode *__restrict__ inner, const uint32_t *__restrict__ leaf_orig,
-                    const float *__restrict__ data, float *__restrict__ sums, uint32_t *__restrict__ leaf_out,
+                    const float *__restrict__ data, float *sums, uint32_t *__restrict__ leaf_out,
                     const float *sums_in, size_t rows, int cols, int num_trees, int depth, int top_levels, int top_stride, float missing,
                     int vec4_ok, int *__restrict__ error_flag)
 {
@@ -626,7 +626,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
         const int e = t % RING;
 #pragma unroll
         for (int k = 0; k < K; ++k) ring_vals[e * ROWS + k * 64 + lane] = v[k];
-        asm volatile("" ::: "memory");  // values before the flag: a wave's LDS operations are performed in issue order
+        TAHOE_LDS_RELEASE();  // values before the flag: a wave's LDS operations are performed in issue order
         if (lane == 0) ring_ready[e] = (uint32_t)(t + 1);
         if (more) commit_top();  // this wave's reads of its slot are done (in-order LDS)
     }
@@ -1324,7 +1324,10 @@ tahoe_status tahoe_forest_get_info(const tahoe_forest *f, tahoe_forest_info *inf
     info->qring_lds_bytes = (int)qring_lds_bytes(f);
     info->qring_groups = qring_groups(f);
     info->ring_rows = tilering_rows(f) ? tilering_rows(f) : widef_rows(f);
-    info->tilering_lds_bytes = info->ring_rows ? (int)tilering_lds_bytes(f, info->ring_rows) : 0;
+    // (the wide-row float32 form has its own LDS plan: tile + walker slots + ring, or tops image + row slots when streaming)
+    info->tilering_lds_bytes = tilering_rows(f) ? (int)tilering_lds_bytes(f, info->ring_rows) : (int)widef_lds_bytes(f);
+    info->stream_slots = widef_stream_slots(f);
+    info->stream_levels = widef_stream_levels(f);
     info->qring_tile_rows = info->qring_walkers == 0 ? 0 : qwide_rows(f) ? qwide_rows(f) : qring_regions(f) ? 192 : qring_lds_tile(f) ? 128 : 0;
     info->relayout = f->relayout ? 1 : 0;
     info->relayout_swaps = f->relayout_swaps;

@@ -100,6 +100,19 @@ __device__ __forceinline__ void lds_flag_store(uint32_t *p, uint32_t v)
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// Hand-over of values through LDS inside one workgroup: the producer stores its values, then the flag (or bumps a counter);
+// the consumer reads the flag, then the values.  Both sides rely on "the LDS performs one wave's operations in issue order"
+// and need only keep the COMPILER from reordering (TAHOE_LDS_RELEASE / TAHOE_LDS_ACQUIRE = compiler barriers).  Building with
+// -DTAHOE_RING_RELEASE_ACQUIRE (make RING_FENCES=1) drains the wave's LDS queue at both points instead, so that a suspected
+// ring failure can be bisected in one run (costs ~2 % on K3).
+#ifdef TAHOE_RING_RELEASE_ACQUIRE
+#define TAHOE_LDS_RELEASE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define TAHOE_LDS_ACQUIRE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define TAHOE_LDS_RELEASE() asm volatile("" ::: "memory")
+#define TAHOE_LDS_ACQUIRE() asm volatile("" ::: "memory")
+#endif
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is per function and process-wide, not per handle: always raise it to
 // the device limit (less the kernel's static LDS), so that handles of different shapes can coexist in one process.
 inline hipError_t allow_max_lds(const void *fn, int limit)
@@ -151,6 +164,9 @@ void pipeline_destroy(tahoe_forest *f);
 // TILERING for rows too wide for a 64-row float32 tile (widef.hip)
 tahoe_status widef_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner, const std::vector<float> &h_leaf);
 int widef_rows(const tahoe_forest *f);  // rows per tile; 0 = unavailable
+long long widef_lds_bytes(const tahoe_forest *f);   // LDS per workgroup of the form the launch takes
+int widef_stream_slots(const tahoe_forest *f);      // row slots of the row-streaming form; 0 = the tile form runs
+int widef_stream_levels(const tahoe_forest *f);     // ... and the levels of all trees it keeps in LDS
 tahoe_status widef_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, const float *data, size_t rows, hipStream_t stream,
                           const float *sums_in);
 void widef_destroy(tahoe_forest *f);

@@ -65,7 +65,7 @@ template <int NWALK, bool WRITE_LEAF, bool LDSX, bool NARROW = false, bool EXCH 
           bool SPLIT = false, int BATCH = (RING >= 2 * kQBatch ? kQBatch : RING / 2)>
 __global__ void __launch_bounds__((NWALK + 1) * 64)
     qring_kernel(const uint16_t *__restrict__ xq, const uint32_t *__restrict__ top, const uint4 *__restrict__ blocks,
-                 const uint32_t *__restrict__ qinner, const uint32_t *__restrict__ leaf_orig, float *__restrict__ sums,
+                 const uint32_t *__restrict__ qinner, const uint32_t *__restrict__ leaf_orig, float *sums,
                  uint32_t *__restrict__ leaf_out, size_t rows, int cols, int num_trees, int depth, int top_levels,
                  int top_stride, const uint32_t *__restrict__ chunk_flags, int *__restrict__ error_flag,
                  const float *sums_in, int tree_base, int total_trees, int cshift, float *__restrict__ leafbuf, size_t leaf_stride,
@@ -145,7 +145,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                 __builtin_amdgcn_s_sleep(TAHOE_CONS_SLEEP);
             }
             if (dead) break;
-            asm volatile("" ::: "memory");  // the values are read after the flags
+            TAHOE_LDS_ACQUIRE();  // the values are read after the flags
             for (int j = 0; j < nb; ++j) {
                 const int e = (t0 + j) % RING;
 #pragma unroll
@@ -248,7 +248,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
             const int e = t % RING;
     #pragma unroll
             for (int k = 0; k < K; ++k) ring_vals[e * TR + k * 64 + lane] = v[k];
-            asm volatile("" ::: "memory");  // values before the flag: a wave's LDS operations are performed in issue order
+            TAHOE_LDS_RELEASE();  // values before the flag: a wave's LDS operations are performed in issue order
             if (lane == 0) lds_flag_store(&ring_ready[e], (uint32_t)(t + 1));
         };
         int t_p = -1;  // tree whose bottom blocks are in flight
@@ -360,7 +360,7 @@ constexpr int kWideRingBytesK = 16384;  // ring of the KG = 3 form
 template <int RT, bool WRITE_LEAF, int KG = 1, int RB = kWideRingBytes>
 __global__ void __launch_bounds__(16 * 64)
     qwide_kernel(const uint16_t *__restrict__ xq, const uint32_t *__restrict__ top, const uint4 *__restrict__ blocks,
-                 const uint32_t *__restrict__ qinner, const uint32_t *__restrict__ leaf_orig, float *__restrict__ sums,
+                 const uint32_t *__restrict__ qinner, const uint32_t *__restrict__ leaf_orig, float *sums,
                  uint32_t *__restrict__ leaf_out, size_t rows, int cols, int num_trees, int depth, int top_levels,
                  int top_stride, const uint32_t *__restrict__ chunk_flags, int *__restrict__ error_flag,
                  const float *sums_in, int tree_base, int total_trees, int slot_bytes, int lw, int cshift)
@@ -414,7 +414,7 @@ __global__ void __launch_bounds__(16 * 64)
                 __builtin_amdgcn_s_sleep(2);
             }
             if (dead) break;
-            asm volatile("" ::: "memory");  // the values are read after the flags
+            TAHOE_LDS_ACQUIRE();  // the values are read after the flags
             if (lane < RT) {  // tree order; eight loads in flight, eight adds in order (one tree at a time, a load's
                                // latency per tree, made this wave the bottleneck of a 16-row tile: 500 trees x ~100 clk)
                 int jj = 0;
@@ -511,7 +511,7 @@ __global__ void __launch_bounds__(16 * 64)
                 const int t = g * TPG + k * TPW + j;
                 if (t < num_trees) ring_vals[(t % RE) * RT + r] = v[k];
             }
-            asm volatile("" ::: "memory");  // values before the flags: a wave's LDS operations are performed in issue order
+            TAHOE_LDS_RELEASE();  // values before the flags: a wave's LDS operations are performed in issue order
 #pragma unroll
             for (int k = 0; k < KG; ++k) {
                 const int t = g * TPG + k * TPW + j;
@@ -593,7 +593,7 @@ __global__ void __launch_bounds__(16 * 64)
 // ------------------------------------------------------------------------------------------------
 // Second step of the SPLIT form: per row, the leaf values of the group's trees in tree order, continuing sums_in.
 __global__ void __launch_bounds__(256) ordered_sum_kernel(const float *__restrict__ leafbuf, size_t leaf_stride, int num_trees,
-                                                          const float *sums_in, float *__restrict__ sums, size_t rows)
+                                                          const float *sums_in, float *sums, size_t rows)
 {
     const size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (row >= rows) return;

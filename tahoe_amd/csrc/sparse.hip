@@ -65,7 +65,7 @@ constexpr int32_t kSIsLeaf = (int32_t)(1u << 31);
 template <bool TILE, bool WRITE_LEAF>
 __global__ void __launch_bounds__(kBlock) sparse_kernel(const tahoe_sparse_node *__restrict__ nodes,
                                                         const int32_t *__restrict__ trees, const float *__restrict__ data,
-                                                        float *__restrict__ sums, uint32_t *__restrict__ leaf_out,
+                                                        float *sums, uint32_t *__restrict__ leaf_out,
                                                         const float *sums_in, size_t rows, int cols, int num_trees, float missing,
                                                         int vec4_ok)
 {
@@ -152,7 +152,7 @@ constexpr int kSSpinLimit = 1 << 22;
 template <int NW, bool WRITE_LEAF>
 __global__ void __launch_bounds__(NW * 64) sparse_top_kernel(const uint2 *__restrict__ cnodes, const int32_t *__restrict__ ctrees,
                                                              const uint32_t *__restrict__ corig, const float *__restrict__ data,
-                                                             float *__restrict__ sums, uint32_t *__restrict__ leaf_out,
+                                                             float *sums, uint32_t *__restrict__ leaf_out,
                                                              const float *sums_in, size_t rows, int cols, int num_trees, float missing,
                                                              int vec4_ok, int *__restrict__ error_flag)
 {
@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(NW * 64) sparse_top_kernel(const uint2 *__rest
                 __builtin_amdgcn_s_sleep(2);
             }
             if (dead) break;
-            asm volatile("" ::: "memory");  // the values are read after the flags
+            TAHOE_LDS_ACQUIRE();  // the values are read after the flags
             for (int j = 0; j < nb; ++j) sum += ring_vals[((t0 + j) % kSRing) * kTileRows + lane];  // tree order
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane == 0) lds_flag_store(consumed, (uint32_t)(t0 + nb));
@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(NW * 64) sparse_top_kernel(const uint2 *__rest
         }
         const int e = t % kSRing;
         ring_vals[e * kTileRows + lane] = v;
-        asm volatile("" ::: "memory");  // values before the flag: a wave's LDS operations are performed in issue order
+        TAHOE_LDS_RELEASE();  // values before the flag: a wave's LDS operations are performed in issue order
         if (lane == 0) lds_flag_store(&ring_ready[e], (uint32_t)(t + 1));
     }
     if (dead && lane == 0) atomicOr(error_flag, 1);
@@ -305,7 +305,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
     sparse_q_kernel(const uint16_t *__restrict__ xq, const uint32_t *__restrict__ qtop, const uint4 *__restrict__ qblocks,
                     const int32_t *__restrict__ qblkoff, const uint32_t *__restrict__ qbotpos, const uint32_t *__restrict__ qblkpos,
                     const int32_t *__restrict__ ctrees, const uint32_t *__restrict__ corig,
-                    float *__restrict__ sums, uint32_t *__restrict__ leaf_out, size_t rows, int cols, int tree_lo, int num_trees,
+                    float *sums, uint32_t *__restrict__ leaf_out, size_t rows, int cols, int tree_lo, int num_trees,
                     int total_trees, const uint32_t *__restrict__ chunk_flags, int *__restrict__ error_flag, const float *sums_in,
                     int cshift, size_t row_begin)
 {
@@ -363,7 +363,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                 __builtin_amdgcn_s_sleep(1);
             }
             if (dead) break;
-            asm volatile("" ::: "memory");  // the values are read after the flags
+            TAHOE_LDS_ACQUIRE();  // the values are read after the flags
             for (int j = 0; j < nb; ++j) {
                 const int e = (t0 + j) % RING;
 #pragma unroll
@@ -472,7 +472,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
             const int e = t % RING;
 #pragma unroll
             for (int k = 0; k < K; ++k) ring_vals[e * TR + k * 64 + lane] = __uint_as_float(entry_p[k]);
-            asm volatile("" ::: "memory");  // values before the flag: a wave's LDS operations are performed in issue order
+            TAHOE_LDS_RELEASE();  // values before the flag: a wave's LDS operations are performed in issue order
             if (lane == 0) lds_flag_store(&ring_ready[e], (uint32_t)(t + 1));
         };
         for (int t = wave; t < num_trees && !dead; t += NWALK) {

@@ -767,3 +767,50 @@ def test_wide_rows_float32_form(env, T, D, C, R, missing_prob):
     cont = oracle.predict_continue(nodes, T, D, data, MISSING, start)
     assert np.array_equal(bits(acc.cpu().numpy()), bits(cont))
     f.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,D,C,R,missing_prob", [
+    (300, 8, 3072, 1003, 0.03),   # K2's shape: five levels of all trees resident, 4 row slots; missing values and NaN
+    (300, 8, 3072, 5, 0.0),       # fewer rows than CUs: one-row workgroups
+    (37, 10, 2052, 333, 0.02),    # rows of 8 DMA pieces + a 16-byte tail piece; levels between the LDS tops and the blocks
+    (1200, 9, 1024, 700, 0.01),   # many trees: few resident levels, four levels from the heap in global memory
+    (65, 3, 640, 4097, 0.0),      # depth 3: the whole tree is one bottom block; 65 trees = two chunks, the second one lane
+    (9, 2, 700, 64, 0.05),        # depth 2: the form is unavailable, the tile form serves
+])
+def test_wide_rows_streaming_form(env, monkeypatch, T, D, C, R, missing_prob):
+    """TAHOE_WSTREAM=1: TILERING on wide rows as the row-streaming kernel (widef.hip, wstream_kernel: tops of all trees resident
+    in LDS, rows through a ring of LDS-DMA slots, lane = tree): leaf indices, sums and continued sums against the oracle."""
+    ta, oracle, torch = env
+    monkeypatch.setenv("TAHOE_WSTREAM", "1")
+    nodes = ta.synth_forest(T, D, C, seed=950 + T, leaf_prob=0.1 if D > 4 else 0.0)
+    data = ta.synth_data(R, C, seed=951 + R, missing_prob=missing_prob, missing=MISSING, nan_prob=missing_prob / 2)
+    if missing_prob and R > 3:
+        data[3, :5] = [np.inf, -np.inf, -0.0, MISSING + 5e-7, MISSING - 2e-6]
+    f = ta.Forest(nodes, T, D, C, missing=MISSING)
+    info = f.info()
+    assert (info.stream_slots >= 3 and info.stream_levels >= 1) if D >= 3 else info.stream_slots == 0
+    assert info.tilering_lds_bytes <= 160 * 1024
+    f.set_strategy(ta.STRATEGY_TILERING)
+    want, want_leaf = oracle.predict(nodes, T, D, data, MISSING, want_leaf=True, threads=8)
+    x = torch.from_numpy(data).cuda()
+    for _ in range(2):  # twice: the handle keeps no state between predicts
+        leaf, sums = f.predict_leaf_idx(x)
+        preds = f.predict_raw(x)
+        f.check()
+        assert np.array_equal(bits(leaf.cpu().numpy()), want_leaf)
+        assert np.array_equal(bits(sums.cpu().numpy()), bits(want))
+        assert np.array_equal(bits(preds.cpu().numpy()), bits(want))
+    start = np.linspace(-2.0, 2.0, R).astype(np.float32)
+    acc = f.predict_accumulate(x, torch.from_numpy(start.copy()).cuda())
+    f.check()
+    assert np.array_equal(bits(acc.cpu().numpy()), bits(oracle.predict_continue(nodes, T, D, data, MISSING, start)))
+    # an unaligned row pointer (rows start 4 bytes into a buffer) cannot be DMA'd in 16-byte pieces: the tile form serves it
+    if R > 1:
+        flat = torch.empty(R * C + 1, dtype=torch.float32, device="cuda")
+        flat[1:] = x.reshape(-1)
+        shifted = flat[1:].view(R, C)
+        assert shifted.data_ptr() % 16 != 0
+        assert np.array_equal(bits(f.predict_raw(shifted).cpu().numpy()), bits(want))
+        f.check()
+    f.close()
