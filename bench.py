@@ -15,7 +15,12 @@ N > 1 (default, --scaling strong): the metric's 1M rows are split by rows, rank 
 --shard trees: the forest's trees are split across ranks instead, every rank sees the same 1M rows, the per-rank sums
     are combined as --tree-mode says (tahoe_amd/sharding.py: allreduce64 | allreduce32 | chain).
 
-Secondary legs in the same JSON line (never part of `value`): BASELINE config 4 ("K4", 8000 trees) both ways --
+At N > 1 the line proves what ran: "collective" carries the backend, the ranks the process group reports, an all-reduce of
+ones that must sum to that number, the device of every rank, and the fastest / slowest rank's step time.
+
+Secondary legs in the same JSON line (never part of `value`; at N > 1 only with --k4, and then every collective step is
+preceded by an all-reduced "everyone is fine" flag so that a failure on one rank cannot strand the others in a collective
+and take the primary line with it): BASELINE config 4 ("K4", 8000 trees) both ways --
 row shards (bit-exact) and tree shards (all-reduce of float64 partials, and the bit-exact chain) -- each with its
 error against a float64 CPU sum on a row sample; at N = 1 they are the one-GPU proxies of the 8-GPU run ("K4 on
 R/8 rows" against "one 1000-tree shard on all R rows").
@@ -139,6 +144,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-host", action="store_true", help="skip the host-resident (PCIe-inclusive) leg")
     ap.add_argument("--no-k4", "--no-tree-leg", dest="no_k4", action="store_true", help="skip the secondary K4 legs")
+    ap.add_argument("--k4", action="store_true", help="N > 1: run the secondary K4 legs too (they contain collectives; off by default there)")
     ap.add_argument("--k4-trees", type=int, default=8000)
     ap.add_argument("--k4-chain", action="store_true",
                     help="N > 1: also time the chained (bit-exact, point-to-point) tree shards of K4; off by default because a stuck "
@@ -208,6 +214,23 @@ def main():
         kw = {} if op is None else {"op": op}
         coll.all_reduce(t, **kw)  # nccl = RCCL over xGMI
 
+    # ---- N > 1: the run proves what it ran on -- ranks the process group reports, an all-reduce of ones over them, the
+    # device of every rank (n_gpus in the line is this count, not an environment variable) ----
+    collective = None
+    if world > 1:
+        ranks_seen = int(dist.get_world_size())
+        ones = torch.ones(1, dtype=torch.float64, device="cuda")
+        all_reduce(ones)
+        devs = torch.zeros(ranks_seen, dtype=torch.float64, device="cuda")
+        devs[dist.get_rank()] = float(device_index)
+        all_reduce(devs)
+        collective = {"backend": "nccl (RCCL)" if backend == "nccl" else backend, "world_size_env": world, "ranks_seen": ranks_seen,
+                      "allreduce_ones_sum": float(ones.item()), "allreduce_ones_ok": bool(ones.item() == float(ranks_seen)),
+                      "device_of_rank": [int(v) for v in devs.cpu().tolist()],
+                      "device_name": torch.cuda.get_device_name(device_index)}
+        if ranks_seen != args.gpus or not collective["allreduce_ones_ok"]:
+            raise SystemExit(f"bench: --gpus {args.gpus} but the process group has {ranks_seen} ranks / all-reduce of ones = {ones.item()}")
+
     T, D, C, R = args.trees, args.depth, args.cols, args.rows
     nodes = ta.synth_forest(T, D, C, seed=42)
     if args.relayout:
@@ -262,6 +285,15 @@ def main():
         all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def agree(ok):
+        """Every rank learns whether ALL ranks are fine (one all-reduce of a flag): a failure on one rank makes every rank
+        leave the leg together instead of stranding the others in the next collective."""
+        if world == 1:
+            return bool(ok)
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device="cuda")
+        all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
+
     for _ in range(args.warmup):
         step()
     forest.set_profiling(args.steps if not (tree_sharded and args.tree_mode == "chain") else 0)
@@ -270,7 +302,13 @@ def main():
     for _ in range(args.steps):
         step()
     fence()
-    dt = max_over_ranks(time.perf_counter() - t0)
+    dt_local = time.perf_counter() - t0
+    dt = max_over_ranks(dt_local)
+    if world > 1:  # the spread over the ranks, for the record (value uses the slowest)
+        t_min = torch.tensor([dt_local], dtype=torch.float64, device="cuda")
+        all_reduce(t_min, op=dist.ReduceOp.MIN)
+        collective["ms_per_step_fastest_rank"] = round(float(t_min.item()) / args.steps * 1e3, 4)
+        collective["ms_per_step_slowest_rank"] = round(dt / args.steps * 1e3, 4)
     forest.check()  # a raised error flag (bounded ring wait) voids the run
     kernel_ms = forest.kernel_times_ms()
     prepass_ms = forest.prepass_times_ms()
@@ -305,6 +343,8 @@ def main():
     compulsory = my_rows * C * 4 + my_T * n_per_tree * (4 + info.bits_bytes) + my_rows * 4
     roofline = {
         "bound": "hbm", "kernel": f"{strategy_name}: quantise pre-pass + walk" if quant_ms else f"{strategy_name}_kernel",
+        "bound_note": "the contract's two bounds are hbm | mfma and this path has no MFMA; what physically binds the walk is vector-"
+                      "instruction issue + per-wave latency (LDS-resident), the pre-pass the texture path -- see physical",
         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBPS, 4),
         "model_bytes_ratio": round(achieved / HBM_PEAK_GBPS, 4),
@@ -329,9 +369,10 @@ def main():
     # ---- secondary legs: BASELINE config 4 ("K4": 8000 trees).  Which split serves it?  Measured both ways, each with
     # its error against a float64 CPU sum on a row sample.  N = 1: the one-GPU proxies of the 8-GPU run. ----
     k4 = None
-    if not args.no_k4 and not tree_sharded and (T, D, C, R) == (1000, 12, 256, 1_000_000):
+    want_k4 = (not args.no_k4 and (T, D, C, R) == (1000, 12, 256, 1_000_000)) if world == 1 else args.k4
+    if want_k4 and not tree_sharded:
         try:
-            k4 = k4_legs(args, ta, sharding, torch, coll, dist, world, rank, fence, max_over_ranks, stream)
+            k4 = k4_legs(args, ta, sharding, torch, coll, dist, world, rank, fence, max_over_ranks, stream, agree)
         except Exception as err:  # the primary line must survive a failure of a secondary leg
             k4 = {"error": f"{type(err).__name__}: {err}"}
 
@@ -392,16 +433,19 @@ def main():
         sharding_name = "none" if world == 1 else (f"trees/{args.tree_mode}" if tree_sharded else "rows")
         out = {
             "metric": "samples/sec, 1000-tree depth-12 forest @1M rows (batched tree-ensemble traversal)",
-            "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "value": round(value, 1), "unit": "samples/s", "n_gpus": collective["ranks_seen"] if collective else 1, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "us_per_batch": round(ms_per_step * 1e3, 1),
             "higher_is_better": True,
-            "scaling": "weak" if (weak or world == 1) else "strong",
+            # the default split at N > 1 is strong (the metric's rows over the ranks); N = 1 carries the same label so that the
+            # driver's N = 1 row is comparable with its N > 1 rows
+            "scaling": "weak" if weak else "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"K3: synthetic forest {T} trees depth {D}, {C} features, {R} rows"
                                    + (" per GPU" if weak else (f" split over {world} GPUs" if world > 1 else "")),
                        "trees": T, "depth": D, "cols": C, "rows_per_step": total_rows, "rows_per_gpu": my_rows,
                        "sharding": sharding_name, "strategy": strategy_name,
                        **({"relayout_swaps": int(info.relayout_swaps)} if args.relayout else {})},
+            "collective": collective,
             "roofline": roofline,
             "cpu_baseline": cpu,
             "host_pipeline": host_leg,
@@ -412,7 +456,7 @@ def main():
         dist.destroy_process_group()
 
 
-def k4_legs(args, ta, sharding, torch, coll, dist, world, rank, fence, max_over_ranks, stream):
+def k4_legs(args, ta, sharding, torch, coll, dist, world, rank, fence, max_over_ranks, stream, agree):
     """BASELINE config 4 both ways.  Every rank builds the 8000-tree forest description (counter-based generator: tree t
     is the same everywhere) and keeps what its role needs.  The CPU oracle appears here only as the checker of the sums
     the timed launches produced (never inside a timed region)."""
@@ -454,32 +498,58 @@ def k4_legs(args, ta, sharding, torch, coll, dist, world, rank, fence, max_over_
     # (a) row shards: the whole forest on every rank, R/N rows each (N = 1: R/8 rows = one of eight ranks' share)
     n_ranks_modelled = world if world > 1 else G
     lo, hi = sharding.shard_bounds(R, rank if world > 1 else 0, n_ranks_modelled)
-    xa = torch.from_numpy(ta.synth_data(hi - lo, C, seed=43, first_row=lo)).cuda()
-    pa = torch.empty(hi - lo, dtype=torch.float32, device="cuda")
-    fa = ta.Forest(nodes4, T4, D, C, missing=MISSING)
-    fa.reserve(hi - lo)
-    ta_s = timed(lambda: fa.predict(xa, pa, stream=stream))
-    fa.check()
-    leg = {"sharding": "rows", "collective": "none", "rows_per_gpu": hi - lo, "trees_per_gpu": T4,
-           "tree_groups_per_gpu": fa.info().qring_groups, "ms_per_step": round(ta_s * 1e3, 4),
-           "value": round(R / ta_s, 1), "unit": "samples/s",
-           "value_means": f"{R} rows / time of one rank's {hi - lo} rows" + ("" if world > 1 else f" (projection to {G} GPUs)")}
-    if rank == 0:
-        e, _, _ = errors(pa[:sample].cpu().numpy(), xa[:sample].cpu().numpy(), ncpu)
-        leg.update(e)
-        if not e["bit_identical_to_cpu_f32"]:  # reported, not raised: the other ranks are on their way into the next collective
-            leg["error"] = "K4 row shard: sums differ from the CPU oracle"
+    fa = xa = pa = None
+    try:  # local part: no collective inside
+        xa = torch.from_numpy(ta.synth_data(hi - lo, C, seed=43, first_row=lo)).cuda()
+        pa = torch.empty(hi - lo, dtype=torch.float32, device="cuda")
+        fa = ta.Forest(nodes4, T4, D, C, missing=MISSING)
+        fa.reserve(hi - lo)
+        fa.predict(xa, pa, stream=stream)
+        fa.check()
+        ok, why = True, None
+    except Exception as err:
+        ok, why = False, f"{type(err).__name__}: {err}"
+    if agree(ok):
+        ta_s = timed(lambda: fa.predict(xa, pa, stream=stream))
+        leg = {"sharding": "rows", "collective": "none", "rows_per_gpu": hi - lo, "trees_per_gpu": T4,
+               "tree_groups_per_gpu": fa.info().qring_groups, "ms_per_step": round(ta_s * 1e3, 4),
+               "value": round(R / ta_s, 1), "unit": "samples/s",
+               "value_means": f"{R} rows / time of one rank's {hi - lo} rows" + ("" if world > 1 else f" (projection to {G} GPUs)")}
+        if rank == 0:
+            try:
+                fa.check()
+                e, _, _ = errors(pa[:sample].cpu().numpy(), xa[:sample].cpu().numpy(), ncpu)
+                leg.update(e)
+                if not e["bit_identical_to_cpu_f32"]:  # reported, not raised
+                    leg["error"] = "K4 row shard: sums differ from the CPU oracle"
+            except Exception as err:
+                leg["error"] = f"{type(err).__name__}: {err}"
+    else:
+        leg = {"sharding": "rows", "error": why or "another rank failed to set this leg up"}
     legs["row_sharded"] = leg
-    fa.close()
-    del fa, pa
+    if fa is not None:
+        fa.close()
+    del fa, pa, xa
 
     # (b) tree shards: T4/N trees per rank, all R rows; N = 1: one of eight shards (the all-reduce is not in the time)
-    x4 = torch.from_numpy(ta.synth_data(R, C, seed=43, first_row=0)).cuda()
-    p4 = torch.empty(R, dtype=torch.float32, device="cuda")
     n_shards = world if world > 1 else G
     s_lo, s_hi = sharding.shard_bounds(T4, rank if world > 1 else 0, n_shards)
-    fb = ta.Forest(nodes4[s_lo * per_tree: s_hi * per_tree], s_hi - s_lo, D, C, missing=MISSING)
-    fb.reserve(R)
+    fb = x4 = p4 = None
+    try:
+        x4 = torch.from_numpy(ta.synth_data(R, C, seed=43, first_row=0)).cuda()
+        p4 = torch.empty(R, dtype=torch.float32, device="cuda")
+        fb = ta.Forest(nodes4[s_lo * per_tree: s_hi * per_tree], s_hi - s_lo, D, C, missing=MISSING)
+        fb.reserve(R)
+        fb.predict_raw(x4, p4, stream=stream)
+        fb.check()
+        ok, why = True, None
+    except Exception as err:
+        ok, why = False, f"{type(err).__name__}: {err}"
+    if not agree(ok):
+        legs["tree_sharded_allreduce64"] = {"sharding": "trees", "error": why or "another rank failed to set this leg up"}
+        if fb is not None:
+            fb.close()
+        return legs
     for mode in (("allreduce64", "chain") if (world > 1 and args.k4_chain) else ("allreduce64",)):
         if world > 1:
             tsf = sharding.TreeShardedForest.__new__(sharding.TreeShardedForest)
@@ -490,24 +560,35 @@ def k4_legs(args, ta, sharding, torch, coll, dist, world, rank, fence, max_over_
             tb_s = timed(lambda: tsf.predict_sums(x4, p4))
         else:
             tb_s = timed(lambda: fb.predict_raw(x4, p4, stream=stream))
-        fb.check()
         leg = {"sharding": "trees", "combine": mode, "rows_per_gpu": R, "trees_per_gpu": s_hi - s_lo,
                "ms_per_step": round(tb_s * 1e3, 4), "value": round(R / tb_s, 1), "unit": "samples/s",
                "collective": ("one all-reduce of 8 B/row (float64 partials)" if mode == "allreduce64" else
                               f"point-to-point hand-over of 4 B/row in chunks of {args.chunk_rows} rows") if world > 1 else
                              "not in the time (1 GPU: one of 8 shards); 8 MB all-reduce over xGMI expected << 1 ms"}
+        try:
+            fb.check()
+            ok, why = True, None
+        except Exception as err:
+            ok, why = False, f"{type(err).__name__}: {err}"
+        if not agree(ok):
+            leg["error"] = why or "another rank's forest raised its error flag"
+            legs["tree_sharded_" + mode] = leg
+            break
         if world > 1:
             got = p4[:sample].clone()
             if mode == "chain":  # the last rank of the chain holds the sums: hand the checked rows to rank 0, which reports
                 coll.broadcast(got, src=world - 1)
             if rank == 0:
-                e, exact, a = errors(got.cpu().numpy(), x4[:sample].cpu().numpy(), ncpu)
-                if mode == "chain" and not e["bit_identical_to_cpu_f32"]:
-                    leg["error"] = "K4 chained tree shards: sums differ from the CPU oracle"
-                if mode == "allreduce64":
-                    bound = sharding.sum_error_bound(a, exact, trees_per_shard=(T4 + world - 1) // world)
-                    e["within_stated_bound"] = bool(np.all(np.abs(got.cpu().numpy().astype(np.float64) - exact) <= bound))
-                leg.update(e)
+                try:
+                    e, exact, a = errors(got.cpu().numpy(), x4[:sample].cpu().numpy(), ncpu)
+                    if mode == "chain" and not e["bit_identical_to_cpu_f32"]:
+                        leg["error"] = "K4 chained tree shards: sums differ from the CPU oracle"
+                    if mode == "allreduce64":
+                        bound = sharding.sum_error_bound(a, exact, trees_per_shard=(T4 + world - 1) // world)
+                        e["within_stated_bound"] = bool(np.all(np.abs(got.cpu().numpy().astype(np.float64) - exact) <= bound))
+                    leg.update(e)
+                except Exception as err:
+                    leg["error"] = f"{type(err).__name__}: {err}"
         legs["tree_sharded_" + mode] = leg
     if world == 1:
         # accuracy of the 8-shard all-reduce, emulated on this GPU on the row sample: eight shard forests, float64 combine

@@ -657,17 +657,17 @@ tahoe_status widef_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner,
     if (const char *e2 = getenv("TAHOE_WSTREAM")) knob = atoi(e2);
     if (knob == 1 && cols % 4 == 0 && cols <= 32768 && T <= (size_t)1 << 20 && De >= 3) {
         const int ts = (int)((T + 3) & ~(size_t)3);
-        int s_lw = 0, s_slots = 0;
+        int s_lw = -1, s_slots = 0;  // (depth 3: no resident level at all, the whole tree is its one bottom block)
         for (int min_slots : {4, 3}) {
-            for (int l = std::min(De - 3, 10); l >= 1 && !s_lw; --l)
+            for (int l = std::min(De - 3, 10); l >= 0 && s_lw < 0; --l)
                 if (ws_lds(cols, (int)T, l, ts, min_slots) <= f->lds_limit) s_lw = l;
-            if (s_lw) {
+            if (s_lw >= 0) {
                 s_slots = min_slots;
                 while (s_slots < 16 && ws_lds(cols, (int)T, s_lw, ts, s_slots + 1) <= f->lds_limit) ++s_slots;
                 break;
             }
         }
-        if (s_lw) {
+        if (s_lw >= 0) {
             const size_t nlv = ((size_t)1 << s_lw) - 1;
             const size_t img = (size_t)ws_img_bytes(s_lw, ts);
             std::vector<unsigned char> h_img(img, 0);

@@ -1,8 +1,11 @@
-// ./TahoeSharded <model> <data> [gpus] [--emulate K] [--mode allreduce64|allreduce32|chain] [--chunk ROWS]
-// A forest split by trees over the GPUs of one node (north_star): one process drives G devices; device g
-// holds trees [T*g/G, T*(g+1)/G) and a copy of all rows.  Plain C++ on the C ABI + rccl.h; the HIP types appear only as
-// the stream argument of the collective.  Three ways to combine the per-device sums (tahoe_amd/sharding.py has the
-// same three for one process per GPU):
+// ./TahoeSharded <model> <data> [gpus] [--emulate K] [--mode rows|allreduce64|allreduce32|chain] [--chunk ROWS]
+// A forest on the GPUs of one node (north_star): one process drives G devices.  Plain C++ on the C ABI +
+// rccl.h; the HIP types appear only as the stream argument of the collective.
+//   rows                   what choose_sharding (tahoe_amd/sharding.py) picks whenever the forest fits one GPU: every device
+//                          holds the WHOLE forest and rows [R*g/G, R*(g+1)/G); no data-path collective, every sum is the
+//                          sequential float32 sum of predict_on_cpu, bit for bit.
+// The other three split the forest by trees: device g holds trees [T*g/G, T*(g+1)/G) and a copy of all rows; three ways to
+// combine the per-device sums (tahoe_amd/sharding.py has the same three for one process per GPU):
 //   allreduce64 (default)  per-device sequential float32 partial sums, widened to float64, ONE ncclAllReduce of 8 bytes
 //                          per row over RCCL / xGMI, rounded to float32 once.  Not bit-identical to the CPU's single
 //                          sequential float32 sum; checked against a float64 CPU sum with the bound
@@ -54,7 +57,7 @@ static float cpu_tree(const tahoe_dense_node *root, const float *row, float miss
 int main(int argc, char **argv)
 {
     if (argc < 3) {
-        printf("usage: %s <model> <data> [gpus] [--emulate K] [--mode allreduce64|allreduce32|chain] [--chunk ROWS]\n", argv[0]);
+        printf("usage: %s <model> <data> [gpus] [--emulate K] [--mode rows|allreduce64|allreduce32|chain] [--chunk ROWS]\n", argv[0]);
         return 2;
     }
     int want_gpus = 0, emulate = 0;
@@ -70,7 +73,7 @@ int main(int argc, char **argv)
         else
             want_gpus = atoi(argv[i]);
     }
-    if (mode != "allreduce64" && mode != "allreduce32" && mode != "chain") {
+    if (mode != "rows" && mode != "allreduce64" && mode != "allreduce32" && mode != "chain") {
         fprintf(stderr, "unknown --mode %s\n", mode.c_str());
         return 2;
     }
@@ -85,7 +88,9 @@ int main(int argc, char **argv)
     OK(tahoe_device_count(&ndev));
     int G = emulate > 0 ? emulate : (want_gpus > 0 ? want_gpus : ndev);
     if (emulate == 0 && G > ndev) G = ndev;
-    if (G > T) G = T > 0 ? T : 1;
+    const bool by_rows = mode == "rows";
+    if (!by_rows && G > T) G = T > 0 ? T : 1;
+    if (by_rows && G > R) G = R > 0 ? R : 1;
     if (G < 1) G = 1;
     printf("%d trees of depth %d, %d rows x %d cols, %d shard(s)%s, mode %s\n", T, D, R, C, G, emulate ? " emulated on device 0" : "",
            mode.c_str());
@@ -98,10 +103,15 @@ int main(int argc, char **argv)
     std::vector<float *> data_d((size_t)G, nullptr), sums_d((size_t)G, nullptr);
     std::vector<double *> wide_d((size_t)G, nullptr);
     std::vector<int> devs((size_t)G), shard_trees((size_t)G);
+    std::vector<size_t> row_lo((size_t)G, 0), row_n((size_t)G, rows);  // the rows device g predicts
     for (int g = 0; g < G; ++g) {
         devs[(size_t)g] = emulate ? 0 : g;
         OK(tahoe_device_set(devs[(size_t)g]));
-        const int lo = (int)((long long)T * g / G), hi = (int)((long long)T * (g + 1) / G);
+        const int lo = by_rows ? 0 : (int)((long long)T * g / G), hi = by_rows ? T : (int)((long long)T * (g + 1) / G);
+        if (by_rows) {
+            row_lo[(size_t)g] = rows * (size_t)g / (size_t)G;
+            row_n[(size_t)g] = rows * (size_t)(g + 1) / (size_t)G - row_lo[(size_t)g];
+        }
         shard_trees[(size_t)g] = hi - lo;
         tahoe_forest_params p;
         memset(&p, 0, sizeof(p));
@@ -112,7 +122,12 @@ int main(int argc, char **argv)
         p.missing = missing;
         OK(tahoe_forest_create(&shard[(size_t)g], nodes + (size_t)lo * per_tree, &p));
         OK(tahoe_stream_create(&stream[(size_t)g]));
-        if (emulate && g > 0) {
+        if (by_rows) {  // only this device's rows travel
+            const size_t nb = std::max<size_t>(row_n[(size_t)g], 1) * (size_t)C * sizeof(float);
+            OK(tahoe_device_alloc((void **)&data_d[(size_t)g], nb, 0));
+            OK(tahoe_copy_to_device(data_d[(size_t)g], data + row_lo[(size_t)g] * (size_t)C, row_n[(size_t)g] * (size_t)C * sizeof(float),
+                                    stream[(size_t)g]));
+        } else if (emulate && g > 0) {
             data_d[(size_t)g] = data_d[0];
         } else {
             OK(tahoe_device_alloc((void **)&data_d[(size_t)g], dbytes, 0));
@@ -120,10 +135,10 @@ int main(int argc, char **argv)
         }
         OK(tahoe_device_alloc((void **)&sums_d[(size_t)g], rows * sizeof(float), 1));
         if (wide) OK(tahoe_device_alloc((void **)&wide_d[(size_t)g], rows * sizeof(double), 1));
-        OK(tahoe_forest_reserve(shard[(size_t)g], chain ? std::min(chunk, rows) : rows));
+        OK(tahoe_forest_reserve(shard[(size_t)g], chain ? std::min(chunk, rows) : by_rows ? row_n[(size_t)g] : rows));
     }
     std::vector<ncclComm_t> comms((size_t)G);
-    const bool use_rccl = !emulate && !chain;
+    const bool use_rccl = !emulate && !chain && !by_rows;
     if (use_rccl) {
         const ncclResult_t r = ncclCommInitAll(comms.data(), G, devs.data());
         if (r != ncclSuccess) {
@@ -177,6 +192,14 @@ int main(int argc, char **argv)
             }
             return;
         }
+        if (by_rows) {  // every device walks the whole forest over its rows; nothing to combine
+            for (int g = 0; g < G; ++g) {
+                OK(tahoe_device_set(devs[(size_t)g]));
+                if (row_n[(size_t)g])
+                    OK(tahoe_forest_predict_raw(shard[(size_t)g], sums_d[(size_t)g], data_d[(size_t)g], row_n[(size_t)g], stream[(size_t)g]));
+            }
+            return;
+        }
         for (int g = 0; g < G; ++g) {  // every device walks its trees over all rows
             OK(tahoe_device_set(devs[(size_t)g]));
             OK(tahoe_forest_predict_raw(shard[(size_t)g], sums_d[(size_t)g], data_d[(size_t)g], rows, stream[(size_t)g]));
@@ -212,7 +235,13 @@ int main(int argc, char **argv)
     for (int g = 0; g < G; ++g) OK(tahoe_forest_check(shard[(size_t)g], stream[(size_t)g]));
 
     std::vector<float> total(rows, 0.f), part(rows);
-    if (chain) {  // the last device holds the result
+    if (by_rows) {  // every device holds the finished sums of its rows
+        for (int g = 0; g < G; ++g) {
+            OK(tahoe_device_set(devs[(size_t)g]));
+            if (row_n[(size_t)g])
+                OK(tahoe_copy_to_host(total.data() + row_lo[(size_t)g], sums_d[(size_t)g], row_n[(size_t)g] * sizeof(float), stream[(size_t)g]));
+        }
+    } else if (chain) {  // the last device holds the result
         OK(tahoe_device_set(devs[(size_t)G - 1]));
         OK(tahoe_copy_to_host(total.data(), sums_d[(size_t)G - 1], rows * sizeof(float), stream[(size_t)G - 1]));
     } else if (emulate) {  // the all-reduce's arithmetic on the host, shard order
@@ -232,7 +261,7 @@ int main(int argc, char **argv)
         OK(tahoe_device_set(devs[0]));
         OK(tahoe_copy_to_host(total.data(), sums_d[0], rows * sizeof(float), stream[0]));
     }
-    printf("Exec.Time/Sample with %d tree shard(s) is %f us (%.3f ms per batch)\n", G, us / (double)R, us / 1e3);
+    printf("Exec.Time/Sample with %d %s shard(s) is %f us (%.3f ms per batch)\n", G, by_rows ? "row" : "tree", us / (double)R, us / 1e3);
 
     // ---- check.  Reference values per row: the CPU's sequential float32 sum (BaseTahoeTest.h:458-474) and the same
     // sum in float64.  chain (and G = 1): bit-identical to the float32 sum.  all-reduce modes: within the stated bound
@@ -242,6 +271,11 @@ int main(int argc, char **argv)
     const double u = std::ldexp(1.0, -24);
     const double n1 = (double)std::max(max_shard - 1, 0);
     const double gam = n1 * u / (1.0 - n1 * u);
+    // float32 on the wire: the G partials are added in float32 too, in an order RCCL picks; every intermediate rounds a
+    // prefix of the partials, so that step is bounded by gamma(G - 1) * sum_g |partial_g| <= gamma(G - 1) * sum |leaf|
+    // (a bound in |exact| would reject correct runs on rows whose total nearly cancels)
+    const double g1 = (double)std::max(G - 1, 0);
+    const double gam_combine = wide ? 0.0 : g1 * u / (1.0 - g1 * u);
     size_t bad = 0;
     double worst = 0.0, worst_cpu = 0.0, worst_vs_cpu = 0.0;
     for (size_t r = 0; r < rows; ++r) {
@@ -257,10 +291,10 @@ int main(int argc, char **argv)
         worst = std::fmax(worst, err);
         worst_cpu = std::fmax(worst_cpu, std::fabs((double)want - exact));
         worst_vs_cpu = std::fmax(worst_vs_cpu, std::fabs((double)total[r] - (double)want));
-        if (chain || G == 1) {
+        if (chain || by_rows || G == 1) {
             if (memcmp(&total[r], &want, 4) != 0) ++bad;
         } else {
-            const double bound = gam * abs_sum + (wide ? 1.0 : (double)G) * u * std::fabs(exact) + 1e-300;
+            const double bound = (gam + gam_combine) * (1.0 + u) * abs_sum + u * std::fabs(exact) + 1e-300;
             if (!(err <= bound)) ++bad;
         }
     }
@@ -273,7 +307,7 @@ int main(int argc, char **argv)
         for (void *e : done[(size_t)g]) tahoe_event_destroy(e);
         for (void *e : taken[(size_t)g]) tahoe_event_destroy(e);
         tahoe_forest_destroy(shard[(size_t)g]);
-        if (!(emulate && g > 0)) tahoe_device_free(data_d[(size_t)g]);
+        if (by_rows || !(emulate && g > 0)) tahoe_device_free(data_d[(size_t)g]);
         tahoe_device_free(sums_d[(size_t)g]);
         tahoe_device_free(wide_d[(size_t)g]);
         tahoe_stream_destroy(stream[(size_t)g]);

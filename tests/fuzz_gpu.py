@@ -36,9 +36,11 @@ while time.time() < t_end:
         D = int(rng.choice([0, 1, 2, 3, 5, 8, 10, 12])) if C <= 600 else int(rng.choice([2, 3, 6, 8, 10]))
         nodes = ta.synth_forest(T, D, C, seed=int(rng.integers(1 << 30)), leaf_prob=float(rng.choice([0.0, 0.1, 0.3])))
         want, want_leaf = oracle.predict(nodes, T, D, data, MISSING, want_leaf=True, threads=8)
+        stream_form = C > 512 and rng.random() < 0.5  # TILERING as the row-streaming kernel (read at create)
+        os.environ["TAHOE_WSTREAM"] = "1" if stream_form else "0"
         f = ta.Forest(nodes, T, D, C, missing=MISSING)
         strategies = [ta.STRATEGY_AUTO, ta.STRATEGY_DIRECT, ta.STRATEGY_ROWTILE, ta.STRATEGY_TILEBLOCK, ta.STRATEGY_TILERING, ta.STRATEGY_QRING]
-        desc = f"dense T={T} D={D} C={C} R={R} missing={mp}"
+        desc = f"dense T={T} D={D} C={C} R={R} missing={mp}" + (" wstream" if stream_form else "")
     for s in strategies:
         try:
             f.set_strategy(s)

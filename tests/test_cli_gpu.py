@@ -53,7 +53,8 @@ def test_cli_result_json_and_leaf_dump(built, tmp_path):
 
 @pytest.mark.parametrize("args", [["1"], ["1", "--mode", "allreduce32"], ["1", "--mode", "chain", "--chunk", "100"],
                                   ["--emulate", "3"], ["--emulate", "7", "--mode", "allreduce32"],
-                                  ["--emulate", "3", "--mode", "chain", "--chunk", "64"]])
+                                  ["--emulate", "3", "--mode", "chain", "--chunk", "64"],
+                                  ["1", "--mode", "rows"], ["--emulate", "3", "--mode", "rows"], ["--emulate", "7", "--mode", "rows"]])
 def test_sharded_host(built, args):
     """./TahoeSharded: the C++ tree-sharding host (one process, a forest shard per device).  A 1-GPU box can check the
     RCCL path with a single shard (bit-exact) and the partition + combination logic with shards emulated on device 0:
@@ -65,7 +66,7 @@ def test_sharded_host(built, args):
     assert "Results are correct" in r.stdout and "Exec.Time/Sample with" in r.stdout
 
 
-@pytest.mark.parametrize("mode", ["allreduce64", "allreduce32", "chain"])
+@pytest.mark.parametrize("mode", ["allreduce64", "allreduce32", "chain", "rows"])
 def test_sharded_host_1200_trees(built, tmp_path, mode):
     """The same on a forest where float32 association matters (1200 trees): 8 emulated shards.  The gate inside
     TahoeSharded is the float64 bound (all-reduce modes) / bit equality with the sequential float32 sum (chain)."""
@@ -81,7 +82,7 @@ def test_sharded_host_1200_trees(built, tmp_path, mode):
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Results are correct" in r.stdout
-    if mode == "chain":
+    if mode in ("chain", "rows"):
         assert "max |ours - CPU float32 sum| = 0" in r.stdout
 
 

@@ -789,7 +789,8 @@ def test_wide_rows_streaming_form(env, monkeypatch, T, D, C, R, missing_prob):
         data[3, :5] = [np.inf, -np.inf, -0.0, MISSING + 5e-7, MISSING - 2e-6]
     f = ta.Forest(nodes, T, D, C, missing=MISSING)
     info = f.info()
-    assert (info.stream_slots >= 3 and info.stream_levels >= 1) if D >= 3 else info.stream_slots == 0
+    assert (info.stream_slots >= 3 and info.stream_levels == min(info.stream_levels, max(D, 2) - 3)) if D >= 3 else info.stream_slots == 0
+    assert info.stream_levels >= 1 or D <= 3
     assert info.tilering_lds_bytes <= 160 * 1024
     f.set_strategy(ta.STRATEGY_TILERING)
     want, want_leaf = oracle.predict(nodes, T, D, data, MISSING, want_leaf=True, threads=8)
