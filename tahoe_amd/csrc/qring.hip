@@ -834,6 +834,8 @@ tahoe_status qring_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner,
             if (h_real[i] && !std::isnan(h_inner[i].thr)) ++per_feature[h_inner[i].meta & kMetaFidMask];
         const size_t most = *std::max_element(per_feature.begin(), per_feature.end());
         if (most > (size_t)kQMaxTable + kQMaxTable / 2) G = (most + kQMaxTable - 1) / kQMaxTable;  // below 1.5x: try one group first
+        if (const char *k = getenv("TAHOE_QRING_GROUPS"))  // experiments: at least this many groups (K4: 8 groups of 1000 trees
+            G = std::max(G, (size_t)std::max(atoi(k), 1));  // take the bucketed quantise kernel, 4 of 2000 the two-pass one)
     }
     const size_t bytes_before = f->device_bytes;
     for (;;) {

@@ -22,18 +22,7 @@
 #include <type_traits>
 #include <vector>
 
-#include "forest_internal.h"
-
-struct tahoe_wstate {
-    uint2 *ftop = nullptr;     // [T][tstride] {thr bits, meta}: heap node i at entry i + 1, the first 2^lw - 1 nodes
-    uint4 *fblocks = nullptr;  // [T][2^(De-2)][3]
-    int rt = 0, nwalk = 0, lw = 0, tstride = 0;
-    // row-streaming form (wstream_kernel): the first s_lw levels of ALL trees as one LDS image, node-major
-    unsigned char *simg = nullptr;  // thr[2^s_lw - 1][s_ts] f32 | meta[2^s_lw - 1][s_ts] u16, padded to 1 KiB pieces
-    uint4 *sblocks = nullptr;       // [T][2^(De-3)][8]: the last three levels + eight leaves of a subtree in ONE 128-byte line
-    int s_lw = 0, s_ts = 0, s_slots = 0, s_img_bytes = 0, s_q = 0;
-    bool s_on = false;              // the launch prefers it (shape rule or TAHOE_WSTREAM=1)
-};
+#include "widef_internal.h"
 
 namespace tahoe {
 
@@ -255,268 +244,6 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
     if (dead && lane == 0) atomicOr(error_flag, 1);
 }
 
-
-// ================================================================================================
-// Row-streaming form ("WSTREAM", round 3).  The tile form above stages a tile, walks it, and starts over: one workgroup per
-// CU with LDS full, so nothing overlaps the staging (K2: 1.2 GB streamed at 1.5 TB/s, profiles/r03/pmc_k2.json), and every
-// 8-row tile re-stages the tops of all trees from L2 (2.6 x the bytes of the rows).  Here the roles are swapped, the way the
-// reference lays its forest out for "lane = tree" (node-major `reorg` arrays, Struct.h:1911-1923; walker :1035-1071):
-//   * ONE persistent workgroup per CU keeps the first lw levels of ALL trees in LDS for its whole life, node-major:
-//     thr[i][t] f32 and meta[i][t] u16 (fid | def_left << 15).  Lane = tree: the 64 lanes of a wave hold 64 consecutive trees,
-//     so a node read is conflict-free whatever node each lane stands on (bank = t mod 32), the reference's coalescing argument
-//     moved into LDS;
-//   * the rows of the workgroup's share of the batch stream through a ring of S row slots, pulled by ONE loader wave with
-//     LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPRs, non-temporal), Q pieces in flight, rows
-//     published in order through a counter of landed pieces (tools/ubench_wstream.hip: 5.5 - 6.9 TB/s with 4 - 8 slots);
-//   * a walker wave takes item (row k, chunk c) = 64 trees of one row: lw levels from LDS (the row's feature values are
-//     plain LDS reads at per-lane addresses), the levels below from L2: heap records, then the last three levels and the
-//     eight leaves below them as ONE 128-byte line per walk (the tile form's 8-byte record + 48-byte block were 2.3 lines:
-//     the L2 -> L1 line traffic of these gathers, not HBM, is what bounds this shape); the leaf value goes into
-//     vals[k % 8][t]; the last walker of a row frees its slot for the loader;
-//   * a consumer wave adds the 8-row ring of leaf values in tree order, one lane per row, four rows at a time: float32 sums
-//     bit-identical to predict_on_cpu (BaseTahoeTest.h:462-466).
-// The loader's own flag accesses are inline asm: while an LDS-DMA is in flight hipcc puts s_waitcnt vmcnt(0) in front of
-// every LDS access it can see (the DMA is a pending LDS write), which would drain the stream once per row; and its per-piece
-// work is the load alone -- a wave issues one instruction per ~5 clk, per-piece bookkeeping cost 3 x the stream's time.
-// Timing-only ablation builds (make ABLATE=n; results are wrong on purpose; never shipped): 1 = the consumer adds nothing,
-// 2 = no global gathers below the LDS levels, 3 = walkers only pass the rows on, 4 = the loader loads nothing.
-#ifndef TAHOE_WS_ABLATE
-#define TAHOE_WS_ABLATE 0
-#endif
-constexpr int kWsVals = 8;   // rows of leaf values between walkers and consumer
-constexpr int kWsGroup = 4;  // rows the consumer adds at once (one lane each)
-
-__device__ __forceinline__ uint32_t ws_lds_addr(const void *p) { return (uint32_t)(uintptr_t)p; }  // low half of a generic LDS address
-__device__ __forceinline__ uint32_t ws_flag_load_asm(const uint32_t *p)
-{
-    uint32_t v;
-    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(ws_lds_addr(p)) : "memory");
-    return v;
-}
-__device__ __forceinline__ void ws_flag_store_asm(uint32_t *p, uint32_t v)
-{
-    asm volatile("ds_write_b32 %0, %1" ::"v"(ws_lds_addr(p)), "v"(v) : "memory");
-}
-__device__ __forceinline__ void ws_dma16(const unsigned char *src, unsigned char *lds_dst)
-{
-    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)src, (__attribute__((address_space(3))) void *)lds_dst, 16, 0,
-                                     2 /* nt: every row is read once */);
-}
-
-template <int NWALK, bool WRITE_LEAF, int Q>
-__global__ void __launch_bounds__((NWALK + 2) * 64)
-    wstream_kernel(const float *__restrict__ data, const unsigned char *__restrict__ simg, const uint4 *__restrict__ sblocks,
-                   const InnerNode *__restrict__ inner, const uint32_t *__restrict__ leaf_orig, float *sums, uint32_t *__restrict__ leaf_out,
-                   const float *sums_in, size_t rows, int cols, int num_trees, int depth, int lw, int ts, int img_bytes, int S, float missing,
-                   int *__restrict__ error_flag)
-{
-    constexpr int NW = NWALK + 2;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nlv = (1 << lw) - 1;
-    const int tv = (num_trees + 3) & ~3;
-    const int row_bytes = cols * 4;
-    const float *sthr = reinterpret_cast<const float *>(smem);
-    const uint16_t *smeta = reinterpret_cast<const uint16_t *>(smem + (size_t)nlv * ts * 4);
-    float *srows = reinterpret_cast<float *>(smem + img_bytes);
-    float *vals = srows + (size_t)S * cols;
-    uint32_t *landed = reinterpret_cast<uint32_t *>(vals + (size_t)kWsVals * tv);  // DMA pieces of this workgroup's rows in LDS
-    uint32_t *consumed = landed + 1;                                             // rows the consumer has added
-    uint32_t *walked = landed + 2;                                               // [S] chunk-walks finished in the slot, monotone
-    const size_t per = (rows + gridDim.x - 1) / gridDim.x;
-    const size_t r0 = (size_t)blockIdx.x * per;
-    if (r0 >= rows) return;
-    const int n = (int)(rows - r0 < per ? rows - r0 : per);
-    const int nch = (num_trees + 63) >> 6;  // 64-tree chunks per row
-    const int P = (row_bytes + 1023) >> 10;  // DMA pieces per row
-
-    // ---- the resident tops: the image lies in global memory exactly as in LDS ----
-    for (int pc = wave; pc < (img_bytes >> 10); pc += NW) ws_dma16(simg + (size_t)pc * 1024 + lane * 16, smem + (size_t)pc * 1024);
-    if (tid == 0) {
-        *landed = 0u;
-        *consumed = 0u;
-    }
-    if (tid < S) walked[tid] = 0u;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    if (wave == 0) {
-        // ================= loader =================
-        const int p_full = row_bytes >> 10, rem = row_bytes & 1023;
-        int issued = 0, pub = 0;
-        for (int k = 0; k < n; ++k) {
-            const int slot = k % S;
-            if (k >= S) {
-                const uint32_t need = (uint32_t)nch * (uint32_t)(k / S);  // every earlier row of this slot walked
-                if (ws_flag_load_asm(&walked[slot]) < need) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // never block with unpublished pieces in flight
-                    pub = issued;
-                    ws_flag_store_asm(landed, (uint32_t)pub);
-                    int spins = 0;
-                    while (ws_flag_load_asm(&walked[slot]) < need) {
-                        if (++spins > kWfSpinLimit) {
-                            if (lane == 0) atomicOr(error_flag, 1);
-                            return;
-                        }
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                }
-            }
-            const unsigned char *src = reinterpret_cast<const unsigned char *>(data + (r0 + k) * (size_t)cols) + lane * 16;
-            unsigned char *dst = reinterpret_cast<unsigned char *>(srows) + (size_t)slot * row_bytes;
-#if TAHOE_WS_ABLATE != 4
-            for (int p = 0; p < p_full; ++p) ws_dma16(src + p * 1024, dst + p * 1024);
-            if (rem && lane * 16 < rem) ws_dma16(src + p_full * 1024, dst + p_full * 1024);
-#endif
-            issued += P;
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Q) : "memory");  // all but the Q youngest pieces have landed
-            if (issued - Q > pub) {
-                pub = issued - Q;
-                ws_flag_store_asm(landed, (uint32_t)pub);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ws_flag_store_asm(landed, (uint32_t)issued);
-        return;
-    }
-
-    if (wave == 1) {
-        // ================= consumer: ordered accumulation, lane = row of a group of kWsGroup =================
-        bool dead = false;
-        for (int g0 = 0; g0 < n && !dead; g0 += kWsGroup) {
-            const int nb = min(kWsGroup, n - g0);
-            const int k = g0 + min(lane, nb - 1);
-            const uint32_t need = (uint32_t)nch * (uint32_t)(k / S + 1);
-            int spins = 0;
-            for (;;) {
-                const bool ok = lds_flag_load(&walked[k % S]) >= need;
-                if (__ballot(ok) == ~0ull) break;
-                if (++spins > kWfSpinLimit) {
-                    dead = true;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(2);
-            }
-            if (dead) break;
-            TAHOE_LDS_ACQUIRE();  // the values are read after the flags
-            if (lane < nb && TAHOE_WS_ABLATE != 1) {
-                const float *v = vals + (size_t)(k % kWsVals) * tv;
-                float sum = sums_in ? sums_in[r0 + k] : 0.0f;
-                int t = 0;
-                for (; t + 8 <= num_trees; t += 8) {  // tree order: two 16-byte reads in flight, eight adds in order
-                    const float4 a = *reinterpret_cast<const float4 *>(v + t);
-                    const float4 b = *reinterpret_cast<const float4 *>(v + t + 4);
-                    sum += a.x;
-                    sum += a.y;
-                    sum += a.z;
-                    sum += a.w;
-                    sum += b.x;
-                    sum += b.y;
-                    sum += b.z;
-                    sum += b.w;
-                }
-                for (; t < num_trees; ++t) sum += v[t];
-                if (sums) sums[r0 + k] = sum;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the values have been read
-            if (lane == 0) lds_flag_store(consumed, (uint32_t)(g0 + nb));
-        }
-        if (dead && lane == 0) atomicOr(error_flag, 1);
-        return;
-    }
-
-    // ================= walkers: item = (row k, chunk c); lane = tree c * 64 + lane =================
-    const size_t n_inner = ((size_t)1 << depth) - 1;
-    const uint32_t n_blocks = 1u << (depth - 3);  // three-level subtrees
-    const uint32_t first_block_node = n_blocks - 1;
-    bool dead = false;
-    int k = 0, c = wave - 2;
-    while (c >= nch) {
-        c -= nch;
-        ++k;
-    }
-    while (k < n && !dead) {
-        {   // the row is in LDS, and the consumer is done with the ring entry
-            const uint32_t want = (uint32_t)(k + 1) * (uint32_t)P;
-            int spins = 0;
-            while (lds_flag_load(landed) < want || (k >= kWsVals && lds_flag_load(consumed) + kWsVals <= (uint32_t)k)) {
-                if (++spins > kWfSpinLimit) {
-                    dead = true;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            if (dead) break;
-            TAHOE_LDS_ACQUIRE();
-        }
-        const int slot = k % S;
-        const float *xr = srows + (size_t)slot * cols;
-        const int t = c * 64 + lane;
-        const int tt = min(t, num_trees - 1);  // lanes past the last tree repeat it, unused
-        uint32_t i = 0;                       // heap index
-#if TAHOE_WS_ABLATE == 3
-        if (false)
-#endif
-        for (int l = 0; l < lw; ++l) {
-            const float thr = sthr[i * ts + tt];
-            const uint32_t m = smeta[i * ts + tt];
-            const float x = xr[m & 0x7fffu];
-            i = 2u * i + 1u + go_right(x, thr, (m >> 15) != 0u, missing);
-        }
-        uint32_t idx = i;
-#if TAHOE_WS_ABLATE == 2 || TAHOE_WS_ABLATE == 3
-        const uint32_t bsel = 0, j = 0;
-        const float leaf = __uint_as_float(i);
-#else
-        if (lw < depth - 3) {  // the levels between the LDS tops and the bottom blocks: heap records in global memory
-            const InnerNode *tree = inner + (size_t)tt * n_inner;
-            for (int l = lw; l < depth - 3; ++l) {
-                const InnerNode nd = tree[idx];
-                idx = 2u * idx + 1u + go_right(xr[nd.meta & kMetaFidMask], nd.thr, (nd.meta >> 31) != 0u, missing);
-            }
-        }
-        // the last three levels and the leaf: one 128-byte line per walk (five 16-byte loads of the same line)
-        //   q0 {thr0 | thr1 thr2 | thr3}  q1 {thr4 thr5 thr6, meta0 | meta1 << 16}  q2 {meta2 | meta3 << 16, meta4 | meta5 << 16, meta6, -}
-        //   q3 {leaf0..3}  q4 {leaf4..7};  nodes in heap order of the subtree, meta = fid | def_left << 15
-        const uint32_t bsel = idx - first_block_node;
-        const uint4 *bp = sblocks + ((size_t)tt * n_blocks + bsel) * 8;
-#if TAHOE_WS_ABLATE == 5  // three loads inside one 64-byte half-line
-        const uint4 q0 = bp[0], q1 = bp[1], q2 = bp[2], q3 = q0, q4 = q1;
-#elif TAHOE_WS_ABLATE == 6  // one load
-        const uint4 q0 = bp[0], q1 = q0, q2 = q0, q3 = q0, q4 = q0;
-#elif TAHOE_WS_ABLATE == 7  // two loads, one per 64-byte half
-        const uint4 q0 = bp[0], q1 = q0, q2 = q0, q3 = q0, q4 = bp[4];
-#else
-        const uint4 q0 = bp[0], q1 = bp[1], q2 = bp[2], q3 = bp[3], q4 = bp[4];
-#endif
-        const uint32_t m0 = q1.w & 0xffffu;
-        const uint32_t c0 = go_right(xr[m0 & 0x7fffu], __uint_as_float(q0.x), (m0 >> 15) != 0u, missing);
-        const uint32_t thr_b = c0 ? q0.z : q0.y, m_b = c0 ? (q2.x & 0xffffu) : (q1.w >> 16);
-        const uint32_t c1 = go_right(xr[m_b & 0x7fffu], __uint_as_float(thr_b), (m_b >> 15) != 0u, missing);
-        const uint32_t thr_c = c0 ? (c1 ? q1.z : q1.y) : (c1 ? q1.x : q0.w);
-        const uint32_t m_c = c0 ? (c1 ? q2.z : (q2.y >> 16)) : (c1 ? (q2.y & 0xffffu) : (q2.x >> 16));
-        const uint32_t c2 = go_right(xr[m_c & 0x7fffu], __uint_as_float(thr_c), ((m_c >> 15) & 1u) != 0u, missing);
-        const uint32_t la = c0 ? q4.x : q3.x, lb = c0 ? q4.y : q3.y, lc = c0 ? q4.z : q3.z, ld = c0 ? q4.w : q3.w;
-        const uint32_t le = c1 ? lc : la, lf = c1 ? ld : lb;
-        const float leaf = __uint_as_float(c2 ? lf : le);
-        const uint32_t j = 4u * c0 + 2u * c1 + c2;
-#endif
-        if (t < num_trees) vals[(size_t)(k % kWsVals) * tv + t] = leaf;
-        if (WRITE_LEAF) {
-            if (t < num_trees) leaf_out[(r0 + k) * (size_t)num_trees + t] = leaf_orig[(size_t)t * ((size_t)n_blocks * 8) + (size_t)bsel * 8 + j];
-        }
-        TAHOE_LDS_RELEASE();  // values before the counter; the row's last read precedes it too (in-order LDS)
-        if (lane == 0) atomicAdd(&walked[slot], 1u);
-        c += NWALK;
-        while (c >= nch) {
-            c -= nch;
-            ++k;
-        }
-    }
-    if (dead && lane == 0) atomicOr(error_flag, 1);
-}
-
 // ------------------------------------------------------------------------------------------------
 // host side
 static int wf_lw_max(int rt) { return rt == 32 ? 8 : rt == 16 ? 7 : 6; }  // (64 / rt) * 2^lw / 2 <= 256 chunks
@@ -528,30 +255,13 @@ static long long wf_lds(int cols, int rt, int nwalk, int lw)
 }
 
 int widef_rows(const tahoe_forest *f) { return f->wf ? f->wf->rt : 0; }
-
-// ---- row-streaming form ----
-constexpr int kWsWalkers = 14;
-static long long ws_img_bytes(int lw, int ts) { return ((((1LL << lw) - 1) * ts * 6) + 1023) & ~1023LL; }
-static long long ws_lds(int cols, int num_trees, int lw, int ts, int slots)
-{
-    const long long tv = (num_trees + 3) & ~3;
-    return ws_img_bytes(lw, ts) + (long long)slots * cols * 4 + (long long)kWsVals * tv * 4 + (2 + slots) * 4 + 16;
-}
 int widef_stream_slots(const tahoe_forest *f) { return f->wf && f->wf->s_on ? f->wf->s_slots : 0; }
 int widef_stream_levels(const tahoe_forest *f) { return f->wf && f->wf->s_on ? f->wf->s_lw : 0; }
 long long widef_lds_bytes(const tahoe_forest *f)
 {
     const tahoe_wstate *w = f->wf;
     if (!w) return 0;
-    return w->s_on ? ws_lds(f->p.num_cols, f->p.num_trees, w->s_lw, w->s_ts, w->s_slots) : wf_lds(f->p.num_cols, w->rt, w->nwalk, w->lw);
-}
-
-template <int Q>
-static hipError_t ws_allow(int limit)
-{
-    hipError_t e = allow_max_lds(reinterpret_cast<const void *>(&wstream_kernel<kWsWalkers, false, Q>), limit);
-    if (e != hipSuccess) return e;
-    return allow_max_lds(reinterpret_cast<const void *>(&wstream_kernel<kWsWalkers, true, Q>), limit);
+    return w->s_on ? wkey_lds_bytes(f) : wf_lds(f->p.num_cols, w->rt, w->nwalk, w->lw);
 }
 
 void widef_destroy(tahoe_forest *f)
@@ -559,8 +269,7 @@ void widef_destroy(tahoe_forest *f)
     if (!f->wf) return;
     if (f->wf->ftop) (void)hipFree(f->wf->ftop);
     if (f->wf->fblocks) (void)hipFree(f->wf->fblocks);
-    if (f->wf->simg) (void)hipFree(f->wf->simg);
-    if (f->wf->sblocks) (void)hipFree(f->wf->sblocks);
+    wkey_free(f->wf);
     delete f->wf;
     f->wf = nullptr;
 }
@@ -650,82 +359,7 @@ tahoe_status widef_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner,
         : rt == 16 ? (nwalk == 15 ? wf_allow<16, 15>(f->lds_limit) : wf_allow<16, 12>(f->lds_limit))
                    : (nwalk == 15 ? wf_allow<8, 15>(f->lds_limit) : wf_allow<8, 12>(f->lds_limit));
     if (e != hipSuccess) return bad("hipFuncSetAttribute");
-
-    // ---- the row-streaming form: all trees' first levels resident, rows through a ring of slots ----
-    // levels: as many as leave room for >= 4 row slots (3 if that buys a level); rows of 16-byte multiples only
-    int knob = -1;
-    if (const char *e2 = getenv("TAHOE_WSTREAM")) knob = atoi(e2);
-    if (knob == 1 && cols % 4 == 0 && cols <= 32768 && T <= (size_t)1 << 20 && De >= 3) {
-        const int ts = (int)((T + 3) & ~(size_t)3);
-        int s_lw = -1, s_slots = 0;  // (depth 3: no resident level at all, the whole tree is its one bottom block)
-        for (int min_slots : {4, 3}) {
-            for (int l = std::min(De - 3, 10); l >= 0 && s_lw < 0; --l)
-                if (ws_lds(cols, (int)T, l, ts, min_slots) <= f->lds_limit) s_lw = l;
-            if (s_lw >= 0) {
-                s_slots = min_slots;
-                while (s_slots < 16 && ws_lds(cols, (int)T, s_lw, ts, s_slots + 1) <= f->lds_limit) ++s_slots;
-                break;
-            }
-        }
-        if (s_lw >= 0) {
-            const size_t nlv = ((size_t)1 << s_lw) - 1;
-            const size_t img = (size_t)ws_img_bytes(s_lw, ts);
-            std::vector<unsigned char> h_img(img, 0);
-            float *thr = reinterpret_cast<float *>(h_img.data());
-            uint16_t *meta = reinterpret_cast<uint16_t *>(h_img.data() + nlv * ts * 4);
-            for (size_t t = 0; t < T; ++t)
-                for (size_t i = 0; i < nlv; ++i) {
-                    const InnerNode &nd = h_inner[t * n_inner + i];
-                    thr[i * ts + t] = nd.thr;
-                    meta[i * ts + t] = (uint16_t)((nd.meta & 0x7fffu) | ((nd.meta >> 31) << 15));
-                }
-            if ((e = up(&w->simg, h_img)) != hipSuccess) return bad("simg");
-            const size_t nb3 = (size_t)1 << (De - 3), first3 = nb3 - 1;
-            std::vector<uint4> h_sb(T * nb3 * 8, make_uint4(0u, 0u, 0u, 0u));
-            parallel_for(T, 8, [&](size_t t_lo, size_t t_hi) {
-                for (size_t t = t_lo; t < t_hi; ++t) {
-                    const InnerNode *in = &h_inner[t * n_inner];
-                    for (size_t b = 0; b < nb3; ++b) {
-                        size_t nd[7];  // the subtree's nodes in heap order
-                        nd[0] = first3 + b;
-                        for (int q = 0; q < 3; ++q) {
-                            nd[2 * q + 1] = 2 * nd[q] + 1;
-                            nd[2 * q + 2] = 2 * nd[q] + 2;
-                        }
-                        uint32_t thr[7], m16[7];
-                        for (int q = 0; q < 7; ++q) {
-                            memcpy(&thr[q], &in[nd[q]].thr, 4);
-                            m16[q] = (in[nd[q]].meta & 0x7fffu) | ((in[nd[q]].meta >> 31) << 15);
-                        }
-                        uint4 *o = &h_sb[(t * nb3 + b) * 8];
-                        o[0] = make_uint4(thr[0], thr[1], thr[2], thr[3]);
-                        o[1] = make_uint4(thr[4], thr[5], thr[6], m16[0] | (m16[1] << 16));
-                        o[2] = make_uint4(m16[2] | (m16[3] << 16), m16[4] | (m16[5] << 16), m16[6], 0u);
-                        const float *lv = &h_leaf[t * n_leaf + 8 * b];
-                        memcpy(&o[3], lv, 16);
-                        memcpy(&o[4], lv + 4, 16);
-                    }
-                }
-            });
-            if ((e = up(&w->sblocks, h_sb)) != hipSuccess) return bad("sblocks");
-            w->s_lw = s_lw;
-            w->s_ts = ts;
-            w->s_slots = s_slots;
-            w->s_img_bytes = (int)img;
-            const int pieces = (cols * 4 + 1023) / 1024;
-            w->s_q = (long long)(s_slots - 2) * pieces >= 24 ? 24 : 8;
-            // Built and bit-exact, but NOT the default: on K2 it takes 0.91 ms against the tile form's 0.78 (profiles/r03/
-            // wstream_ablation.txt, pmc_k2_wstream.json): the texture path is ~85 % busy in both forms, a divergent 16-byte
-            // gather costs it about a cycle per lane, and five of them per walk (one 128-byte line, re-fetched 1.8 x because 14
-            // walkers' lines in flight overflow the 32-KiB L1) cost more than the tile form's three plus its coalesced top
-            // staging; stream and gathers do not overlap because both sit in that one queue.  TAHOE_WSTREAM=1 selects it.
-            w->s_on = knob == 1;
-            e = ws_allow<24>(f->lds_limit);
-            if (e == hipSuccess) e = ws_allow<8>(f->lds_limit);
-            if (e != hipSuccess) return bad("hipFuncSetAttribute");
-        }
-    }
-    return TAHOE_OK;
+    return wkey_build(f, h_inner, h_leaf);  // the row-streaming form on 16-bit keys (wkey.hip), where it applies
 }
 
 template <int RT, int NWALK>
@@ -752,31 +386,7 @@ tahoe_status widef_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
     if (!w) return fail(TAHOE_ERR_UNSUPPORTED, "the wide-row float32 form is unavailable for this forest");
     if ((rows + 7) / 8 > 0x7fffffffu) return fail(TAHOE_ERR_INVALID_ARG, "too many rows for one launch: %zu", rows);
     const int vec4_ok = (f->p.num_cols % 4 == 0) && ((reinterpret_cast<uintptr_t>(data) & 15u) == 0);
-    if (w->s_on && vec4_ok && rows > 0) {  // the row-streaming form: one persistent workgroup per CU
-        const size_t nch = ((size_t)f->p.num_trees + 63) / 64;
-        const size_t max_per = ((size_t)1 << 30) / nch;  // rows x chunks of one workgroup stay within int
-        size_t grid = std::min<size_t>(rows, (size_t)std::max(f->num_cus, 1));
-        grid = std::max(grid, (rows + max_per - 1) / max_per);
-        const int lds = (int)ws_lds(f->p.num_cols, f->p.num_trees, w->s_lw, w->s_ts, w->s_slots);
-        auto go = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((kWsWalkers + 2) * 64), lds, stream, data, w->simg, w->sblocks, f->inner,
-                               f->leaf_orig, sums, leaf_out, sums_in, rows, f->p.num_cols, f->p.num_trees, f->depth, w->s_lw, w->s_ts,
-                               w->s_img_bytes, w->s_slots, f->p.missing, f->error_flag);
-        };
-        if (w->s_q == 24) {
-            if (leaf_out)
-                go(wstream_kernel<kWsWalkers, true, 24>);
-            else
-                go(wstream_kernel<kWsWalkers, false, 24>);
-        } else {
-            if (leaf_out)
-                go(wstream_kernel<kWsWalkers, true, 8>);
-            else
-                go(wstream_kernel<kWsWalkers, false, 8>);
-        }
-        TAHOE_HIP_TRY(hipGetLastError());
-        return TAHOE_OK;
-    }
+    if (w->s_on && vec4_ok && rows > 0) return wkey_launch(f, sums, leaf_out, data, rows, stream, sums_in);
     if (w->rt == 32) {
         if (w->nwalk == 15)
             wf_launch<32, 15>(f, sums, leaf_out, data, rows, stream, sums_in, vec4_ok);

@@ -1,0 +1,627 @@
+// TILERING for wide rows, row-streaming form on 16-bit keys ("WKEY", round 3).  Replaces, like widef.hip: the walkers / kernels
+// of Struct.h:953-1704 for shapes where a row does not fit shared memory; the layout is the reference's own idea for
+// "lane = tree" -- node-major `reorg` arrays (Struct.h:1911-1923, walker :1035-1071) -- moved into LDS.
+//
+// What the tile form (widef.hip) costs on K2 (500 trees of depth 8, 3072 features; profiles/r03/pmc_k2.json): one workgroup per
+// CU with LDS full, so nothing overlaps the staging of a tile; every 8-row tile re-stages the tops of all trees from L2 (2.6 x
+// the bytes of the rows); and every walk gathers three 16-byte pieces of a bottom block.  The texture path is what binds
+// (TD 73 % busy, HBM at 20 % of its peak): a divergent gather costs it about a cycle per LANE whatever its width.  A first
+// row-streaming form on float32 rows (profiles/r03/wstream_ablation.txt) could keep only five levels of all trees resident
+// beside four 12-KiB rows and needed five gathers per walk: 0.91 ms against the tile form's 0.78.
+//
+// Here every number that is COMPARED is a 16-bit key, so that a row takes 6 KiB and a node 4 bytes:
+//   key(x) = trunc(clamp((x - lo) * scale, 0, 65534)) in float32, [lo, hi] = the range of the forest's finite thresholds,
+//   scale = 65534 / (hi - lo); NaN -> 0; a missing value (|x - missing| <= 1e-6f, tested on the float32 value while it passes
+//   through the loader's registers) -> 0xFFFF.  Every step is monotone in x, so key(x) > key(thr) => x > thr and
+//   key(x) < key(thr) => x < thr: the branch rule of infer_one_tree (BaseTahoeTest.h:450-453) is decided by one integer
+//   compare, bit for bit -- EXCEPT when the two keys are equal, which is rare (1 / 65534 of the thresholds' range apart;
+//   values outside that range sit on its ends) and detected: those lanes fetch the float32 value from the batch and the
+//   float32 threshold from the heap records in global memory and compare them exactly.  The thresholds' keys are computed
+//   ON THE DEVICE at create, by the same instructions as the features' (host and device float arithmetic never have to
+//   agree).  A NaN threshold has key 0xFFFF: never >=, never equal.  (A first version took the upper 16 bits of the float
+//   -- 7 mantissa bits: 0.15 % of the compares tied, 8 % of the wave-levels ran the float32 path, and its two loads per event
+//   cost the texture path as much as a full gather each: 41 % of the kernel's texture-path time, profiles/r03.)
+//   * ONE persistent workgroup per CU keeps the first lw levels of ALL trees in LDS for its whole life, node-major u32 words
+//     key << 16 | fid << 1 | def_left, tree stride a power of two: lane = tree, so a node read is conflict-free whatever node
+//     each lane stands on, the two children of heap position p are one ds_read2st64_b32 at (p << log2(8 stride)) + lane
+//     constant, and a level costs 7 VALU + 2 LDS instructions per 64 walks (the first, portable version of this loop took 45:
+//     the CU issues one vector instruction per cycle, and that -- not memory -- was what bound it);
+//   * kWkLoaders loader waves pull the rows of the workgroup's share of the batch through registers (16-byte loads, two
+//     4-KiB chunks in flight per wave), turn them into keys and store them into a ring of S row slots;
+//   * a walker wave takes item (row k, chunk c) = 64 trees of one row: lw levels from LDS, the last two levels and the leaf
+//     from ONE 32-byte block per walk (two gathers; the tile form's 48-byte float32 block takes three), levels in between
+//     (deep trees only) from the heap records with the float32 rule; leaf value into vals[k % 4][t]; the last walker of a row
+//     frees its slot;
+//   * four consumer waves, one row each at a time, add the leaf values in tree order as the walkers deliver them: float32
+//     sums bit-identical to predict_on_cpu (BaseTahoeTest.h:462-466).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "widef_internal.h"
+
+namespace tahoe {
+
+#ifndef TAHOE_WK_LOADERS
+#define TAHOE_WK_LOADERS 4
+#endif
+#ifndef TAHOE_WK_WALKERS
+#define TAHOE_WK_WALKERS 8
+#endif
+constexpr int kWkLoaders = TAHOE_WK_LOADERS;   // loader waves (= the fewest row slots)
+#ifndef TAHOE_WK_CONSUMERS
+#define TAHOE_WK_CONSUMERS 4
+#endif
+constexpr int kWkConsumers = TAHOE_WK_CONSUMERS;  // consumer waves: consumer q adds rows q, q + NC, ... (one lane per wave: the chain is serial)
+constexpr int kWkVals = 4;                        // rows of leaf values between walkers and consumers (a multiple of kWkConsumers)
+static_assert(kWkVals % kWkConsumers == 0, "a ring entry belongs to one consumer");
+constexpr int kWkMaxItems = 16;                   // items per row (1024 trees in chunks of 64)
+constexpr int kWkWalkers = TAHOE_WK_WALKERS;      // walker waves; 4 + 4 + 8 = 16 waves
+#ifndef TAHOE_WK_CHAINS
+#define TAHOE_WK_CHAINS 2
+#endif
+constexpr int kWkChains = TAHOE_WK_CHAINS;  // 64-tree chunks of one row a walker wave walks at once (chains per lane)
+constexpr int kWkSpinLimit = 1 << 22;
+constexpr uint32_t kWkMissing = 0xFFFFu;
+
+// Timing-only ablation builds (make ABLATE=n; results are wrong on purpose; never shipped): 1 = no bottom-block gathers,
+// 2 = walkers only pass the rows on, 3 = the loaders load nothing, 4 = the consumers add nothing; 5 = 2 + 4 (loaders alone),
+// 6 = 3 + 4 (walkers alone).
+#ifndef TAHOE_WS_ABLATE
+#define TAHOE_WS_ABLATE 0
+#endif
+#define WK_NO_GATHER (TAHOE_WS_ABLATE == 1)
+#define WK_NO_WALK (TAHOE_WS_ABLATE == 2 || TAHOE_WS_ABLATE == 5)
+#define WK_NO_LOAD (TAHOE_WS_ABLATE == 3 || TAHOE_WS_ABLATE == 6)
+#define WK_NO_ADD (TAHOE_WS_ABLATE == 4 || TAHOE_WS_ABLATE == 5 || TAHOE_WS_ABLATE == 6)
+
+// The key of a float given by its bits; the same integer arithmetic on the host (thresholds, at create) and on the device
+// (feature values, in the loader) -- no float operation, so denormal modes cannot make the two disagree.
+// The key of a non-missing value: NaN -> 0 (v_max_f32 returns its other operand), below lo -> 0, above hi -> 65534.
+__device__ __forceinline__ uint32_t wk_key(float x, float lo, float scale)
+{
+    return (uint32_t)fminf(fmaxf((x - lo) * scale, 0.0f), 65534.0f);
+}
+// feature values (in the loader); *ms collects "a missing value was seen"
+__device__ __forceinline__ uint32_t wk_key_x(float x, float lo, float scale, float missing, uint64_t &ms)
+{
+    const bool m = fabsf(x - missing) <= kMissingEps;
+    ms |= __ballot(m);
+    return m ? kWkMissing : wk_key(x, lo, scale);
+}
+// thresholds, at create: the same instructions on the same device
+__global__ void wkey_threshold_keys_kernel(const float *__restrict__ thr, uint16_t *__restrict__ keys, size_t n, float lo, float scale)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = thr[i] != thr[i] ? (uint16_t)kWkMissing : (uint16_t)wk_key(thr[i], lo, scale);
+}
+__device__ __forceinline__ void wk_dma16(const unsigned char *src, unsigned char *lds_dst)
+{
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)src, (__attribute__((address_space(3))) void *)lds_dst, 16, 0, 0);
+}
+
+typedef const uint32_t __attribute__((address_space(3))) *wk_lds_u32;
+typedef const uint16_t __attribute__((address_space(3))) *wk_lds_u16;
+__device__ __forceinline__ uint32_t wk_lds_addr(const void *p) { return (uint32_t)(uintptr_t)p; }  // low half of a generic LDS address
+// p <- 2p + (lane's bit of mask): one v_addc with the mask as carry-in
+__device__ __forceinline__ uint32_t wk_descend(uint32_t p, uint64_t right_mask)
+{
+    uint32_t r;
+    uint64_t carry_out;
+    asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(r), "=&s"(carry_out) : "v"(p), "s"(right_mask));
+    return r;
+}
+
+template <int TSL, bool WRITE_LEAF>
+__global__ void __launch_bounds__((kWkLoaders + kWkConsumers + kWkWalkers) * 64)
+    wkey_kernel(const float *__restrict__ data, const unsigned char *__restrict__ kimg, const uint4 *__restrict__ kblocks,
+                const InnerNode *__restrict__ inner, const uint32_t *__restrict__ leaf_orig, float *sums, uint32_t *__restrict__ leaf_out,
+                const float *sums_in, size_t rows, int cols, int num_trees, int depth, int lw, int img_bytes, int S, float missing,
+                float key_lo, float key_scale, int *__restrict__ error_flag)
+{
+    constexpr int NL = kWkLoaders, NC = kWkConsumers, NW = kWkLoaders + kWkConsumers + kWkWalkers;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tv = (num_trees + 3) & ~3;
+    const int row_bytes = cols * 4;        // of a float32 row in the batch (a multiple of 16)
+    const int slot_bytes = (cols * 2 + 15) & ~15;  // of a row of keys in LDS
+    unsigned char *srows = smem + img_bytes;
+    float *vals = reinterpret_cast<float *>(srows + (size_t)S * slot_bytes);
+    uint32_t *cdone = reinterpret_cast<uint32_t *>(vals + (size_t)kWkVals * tv);  // [NC] row groups consumer q has added
+    uint32_t *row_ready = cdone + NC;                                             // [S] row index + 1 whose keys are in the slot
+    uint32_t *walked = row_ready + S;                                               // [S] chunk-walks finished in the slot, monotone
+    uint32_t *row_ms = walked + S;                                                  // [S] != 0: the row in the slot has a missing value
+    uint32_t *idone = row_ms + S;  // [kWkVals][kWkMaxItems] row index + 1 whose leaf values of that item are in the ring entry
+    const size_t per = (rows + gridDim.x - 1) / gridDim.x;
+    const size_t r0 = (size_t)blockIdx.x * per;
+    if (r0 >= rows) return;
+    const int n = (int)(rows - r0 < per ? rows - r0 : per);
+    const int nch = (num_trees + 63) >> 6;  // 64-tree chunks per row
+    const int nit = (nch + kWkChains - 1) / kWkChains;  // items (kWkChains chunks each) per row
+
+    // ---- the resident tops: the image lies in global memory exactly as in LDS (LDS-DMA: 1 KiB per wave-instruction) ----
+    for (int pc = wave; pc < (img_bytes >> 10); pc += NW) wk_dma16(kimg + (size_t)pc * 1024 + lane * 16, smem + (size_t)pc * 1024);
+    if (tid < NC) cdone[tid] = 0u;
+    if (tid < kWkVals * kWkMaxItems) idone[tid] = 0u;
+    if (tid < S) {
+        row_ready[tid] = 0u;
+        walked[tid] = 0u;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    if (wave < NL) {
+        // ================= loaders: wave j takes rows j, j + NL, ...; a row = up to four chunks of four 1-KiB pieces =================
+        // (Rows of up to three chunks, num_cols <= 3072.)  Chunk c of a row always uses register set c: the raw floats are turned into keys (kept in registers: a quarter of the
+        // raw bytes) as soon as they land, and the next row's chunk c is requested into the freed set at once -- up to a whole
+        // row in flight per wave.  Only then does the wave wait for its slot: what is left on the critical path behind a freed
+        // slot is a dozen ds_write_b64, not the conversion (that wait used to cost as much as the walk of the row).
+        const int cpr = (row_bytes + 4095) >> 12;  // chunks per row, <= 3 (the host checks num_cols <= 3072: 128 VGPRs per lane)
+        bool dead = false;
+        const int k_last = wave + ((n - 1 - wave) / NL) * NL;  // this wave's last row (n > wave is checked below)
+        auto load = [&](float4(&r)[4], int k, int c) {
+            // (a row past this wave's last one: that row again, unused -- a branch around the loads would make hipcc drain
+            // all of them at the next use; pieces past the end of the row re-read its last 16 bytes for the same reason)
+            const unsigned char *src = reinterpret_cast<const unsigned char *>(data + (r0 + min(k, k_last)) * (size_t)cols);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int off = min((c * 4 + u) * 1024 + lane * 16, row_bytes - 16);
+                r[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#if !WK_NO_LOAD
+                r[u] = *reinterpret_cast<const float4 *>(src + off);
+#endif
+            }
+        };
+        uint64_t ms_seen = 0;  // a missing value among the keys of the row under way (any lane)
+        auto convert = [&](uint2(&kk)[4], const float4(&r)[4]) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t k0 = wk_key_x(r[u].x, key_lo, key_scale, missing, ms_seen);
+                const uint32_t k1 = wk_key_x(r[u].y, key_lo, key_scale, missing, ms_seen);
+                const uint32_t k2 = wk_key_x(r[u].z, key_lo, key_scale, missing, ms_seen);
+                const uint32_t k3 = wk_key_x(r[u].w, key_lo, key_scale, missing, ms_seen);
+                kk[u] = make_uint2(k0 | (k1 << 16), k2 | (k3 << 16));
+            }
+        };
+        auto write = [&](const uint2(&kk)[4], unsigned char *dst, int c) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int off = (c * 4 + u) * 1024 + lane * 16;
+                if (off < row_bytes) *reinterpret_cast<uint2 *>(dst + (off >> 1)) = kk[u];
+            }
+        };
+        if (wave >= n) return;
+        float4 raw0[4], raw1[4], raw2[4];
+        uint2 key0[4], key1[4], key2[4];
+        load(raw0, wave, 0);
+        if (cpr > 1) load(raw1, wave, 1);
+        if (cpr > 2) load(raw2, wave, 2);
+        for (int k = wave; k < n && !dead; k += NL) {
+            convert(key0, raw0);
+            load(raw0, k + NL, 0);
+            if (cpr > 1) {
+                convert(key1, raw1);
+                load(raw1, k + NL, 1);
+            }
+            if (cpr > 2) {
+                convert(key2, raw2);
+                load(raw2, k + NL, 2);
+            }
+            const int slot = k % S;
+            if (k >= S) {  // every earlier row of this slot walked?
+                const uint32_t need = (uint32_t)nit * (uint32_t)(k / S);
+                int spins = 0;
+                while (lds_flag_load(&walked[slot]) < need) {
+                    if (++spins > kWkSpinLimit) {
+                        dead = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (dead) break;
+            }
+            unsigned char *dst = srows + (size_t)slot * slot_bytes;
+            write(key0, dst, 0);
+            if (cpr > 1) write(key1, dst, 1);
+            if (cpr > 2) write(key2, dst, 2);
+            if (lane == 0) lds_flag_store(&row_ms[slot], ms_seen != 0ull ? 1u : 0u);
+            ms_seen = 0;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the keys are in LDS
+            if (lane == 0) lds_flag_store(&row_ready[slot], (uint32_t)(k + 1));
+        }
+        if (dead && lane == 0) atomicOr(error_flag, 1);
+        return;
+    }
+
+    if (wave < NL + NC) {
+        // ================= consumers: consumer q adds rows q, q + NC, ... in tree order, item by item as the walkers deliver them ========
+        // (the 500-term dependent chain of a row takes ~4 k cycles; started only when the whole row was walked, it kept the ring
+        // entry busy for that long behind the row and the walkers waited for it: 0.17 of 0.66 ms.  Now it runs beside the walk of
+        // its own row and ends a quarter of that time after it.)
+        const int q = wave - NL;
+        bool dead = false;
+#ifdef TAHOE_WK_CONS_PRIO
+        __builtin_amdgcn_s_setprio(TAHOE_WK_CONS_PRIO);
+#endif
+        for (int k = q; k < n && !dead; k += NC) {
+            const float *v = vals + (size_t)(k % kWkVals) * tv;
+            float sum = 0.0f;
+            if (lane == 0 && sums_in) sum = sums_in[r0 + k];
+            for (int c = 0; c < nit && !dead; ++c) {
+                int spins = 0;
+                while (lds_flag_load(&idone[(k % kWkVals) * kWkMaxItems + c]) != (uint32_t)(k + 1)) {
+                    if (++spins > kWkSpinLimit) {
+                        dead = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (dead) break;
+                TAHOE_LDS_ACQUIRE();  // the values are read after the flag
+                if (lane == 0 && !WK_NO_ADD) {
+                    int t = c * (64 * kWkChains);
+                    const int t_end = min(num_trees, t + 64 * kWkChains);
+                    if (t + 16 <= t_end) {  // tree order; the next sixteen values are read while these sixteen are added
+                        float4 p0 = *reinterpret_cast<const float4 *>(v + t), p1 = *reinterpret_cast<const float4 *>(v + t + 4);
+                        float4 p2 = *reinterpret_cast<const float4 *>(v + t + 8), p3 = *reinterpret_cast<const float4 *>(v + t + 12);
+                        for (;;) {
+                            const bool more = t + 32 <= t_end;
+                            const float *nx = v + (more ? t + 16 : t);
+                            const float4 n0 = *reinterpret_cast<const float4 *>(nx), n1 = *reinterpret_cast<const float4 *>(nx + 4);
+                            const float4 n2 = *reinterpret_cast<const float4 *>(nx + 8), n3 = *reinterpret_cast<const float4 *>(nx + 12);
+                            sum += p0.x;
+                            sum += p0.y;
+                            sum += p0.z;
+                            sum += p0.w;
+                            sum += p1.x;
+                            sum += p1.y;
+                            sum += p1.z;
+                            sum += p1.w;
+                            sum += p2.x;
+                            sum += p2.y;
+                            sum += p2.z;
+                            sum += p2.w;
+                            sum += p3.x;
+                            sum += p3.y;
+                            sum += p3.z;
+                            sum += p3.w;
+                            t += 16;
+                            if (!more) break;
+                            p0 = n0;
+                            p1 = n1;
+                            p2 = n2;
+                            p3 = n3;
+                        }
+                    }
+                    for (; t < t_end; ++t) sum += v[t];
+                }
+            }
+            if (dead) break;
+            if (lane == 0 && sums && !WK_NO_ADD) sums[r0 + k] = sum;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the values have been read
+            if (lane == 0) lds_flag_store(&cdone[q], (uint32_t)(k / NC + 1));
+        }
+        if (dead && lane == 0) atomicOr(error_flag, 1);
+        return;
+    }
+
+    // ================= walkers: item = (row k, kWkChains chunks of 64 trees); chain j of a lane = tree (c * KC + j) * 64 + lane =========
+    constexpr int KC = kWkChains;
+    const size_t n_inner = ((size_t)1 << depth) - 1;
+    const uint32_t n_blocks = 1u << (depth - 2);
+    const uint32_t first_block_node = n_blocks - 1;
+    if (wk_lds_addr(smem) != 0u) {  // the integer LDS addresses below take the tops at LDS address 0 (true without static LDS)
+        if (lane == 0) atomicOr(error_flag, 2);
+        return;
+    }
+    const uint32_t xbase0 = (uint32_t)img_bytes;
+    bool dead = false;
+    int k = 0, c = wave - NL - NC;
+    while (c >= nit) {
+        c -= nit;
+        ++k;
+    }
+    auto walk_item = [&](auto ms_tag, int k, int c, int slot) {
+        constexpr bool MS = decltype(ms_tag)::value;
+        const uint32_t xbase = xbase0 + (uint32_t)slot * (uint32_t)slot_bytes;  // LDS address of the row's keys
+        const float *xrow = data + (r0 + k) * (size_t)cols;  // the float32 row: equal keys and the levels between tops and blocks
+        int t[KC], tt[KC];
+        const InnerNode *tree[KC];
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {
+            t[j] = (c * KC + j) * 64 + lane;
+            tt[j] = min(t[j], num_trees - 1);  // lanes past the last tree repeat it, unused
+            tree[j] = inner + (size_t)tt[j] * n_inner;
+        }
+        // right <=> (missing ? !def_left : x >= thr) as a wave mask, on keys; equal keys are decided on the float32 values
+        // (heap0 = the node's 0-based heap index, for its float32 threshold)
+        auto right_mask = [&](uint32_t node, uint32_t key_x, const InnerNode *tr, uint32_t heap0) -> uint64_t {
+            const uint64_t gt = __builtin_amdgcn_uicmp(key_x, node >> 16, 34 /* ICMP_UGT */);
+            uint64_t tie = __builtin_amdgcn_uicmp(key_x, node >> 16, 32 /* ICMP_EQ */);
+            uint64_t right = gt;
+            if (MS) {
+                const uint64_t ms = __builtin_amdgcn_uicmp(key_x, kWkMissing, 32 /* ICMP_EQ */);
+                const uint64_t ndl = __builtin_amdgcn_uicmp(node & 1u, 0u, 32 /* ICMP_EQ: def_left clear */);
+                right = (gt & ~ms) | (ms & ndl);
+                tie &= ~ms;
+            }
+            if (tie != 0ull) {  // rare: the two values fall into the same 1 / 65534 of the thresholds' range
+                bool ge = false;
+                if (__builtin_amdgcn_inverse_ballot_w64(tie)) ge = xrow[(node >> 1) & 0x7fffu] >= tr[heap0].thr;
+                right = (right & ~tie) | (__ballot(ge) & tie);
+            }
+            return right;
+        };
+        auto xkey = [&](uint32_t node) -> uint32_t { return *reinterpret_cast<wk_lds_u16>((node & 0xFFFEu) + xbase); };
+        uint32_t p[KC], node[KC], cbase[KC];  // 1-based heap position, node word, lane constant of the child-pair address
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {
+            p[j] = 1;
+            cbase[j] = 4u * (uint32_t)tt[j] - (4u << TSL);  // children of p: position 2p at ((2p - 1) << TSL) + tt dwords
+            node[j] = lw > 0 ? *reinterpret_cast<wk_lds_u32>(4u * (uint32_t)tt[j]) : 0u;
+        }
+#if WK_NO_WALK
+        if (false)
+#endif
+        if (lw > 0) {
+            for (int l = 0; l < lw - 1; ++l) {
+                // one LDS round trip per level: the feature key of the node and BOTH children (one tree stride apart)
+                uint32_t kx[KC], nl[KC], nr[KC];
+#pragma unroll
+                for (int j = 0; j < KC; ++j) {
+                    kx[j] = xkey(node[j]);
+                    const wk_lds_u32 cp = reinterpret_cast<wk_lds_u32>((p[j] << (TSL + 3)) + cbase[j]);
+                    nl[j] = cp[0];
+                    nr[j] = cp[1 << TSL];
+                }
+#pragma unroll
+                for (int j = 0; j < KC; ++j) {
+                    const uint64_t r = right_mask(node[j], kx[j], tree[j], p[j] - 1u);
+                    p[j] = wk_descend(p[j], r);
+                    node[j] = __builtin_amdgcn_inverse_ballot_w64(r) ? nr[j] : nl[j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < KC; ++j) p[j] = wk_descend(p[j], right_mask(node[j], xkey(node[j]), tree[j], p[j] - 1u));
+        }
+        float leaf[KC];
+        uint32_t bsel[KC], c0[KC], c1[KC];
+#if WK_NO_GATHER || WK_NO_WALK
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {
+            bsel[j] = c0[j] = c1[j] = 0;
+            leaf[j] = __uint_as_float(p[j]);
+        }
+#else
+        uint4 qa[KC], qb[KC];
+        uint32_t idx[KC];
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {
+            idx[j] = p[j] - 1u;  // 0-based heap index on level lw
+            for (int l = lw; l < depth - 2; ++l) {  // deep trees only: the float32 rule on the heap records in global memory
+                const InnerNode nd = tree[j][idx[j]];
+                idx[j] = 2u * idx[j] + 1u + go_right(xrow[nd.meta & kMetaFidMask], nd.thr, (nd.meta >> 31) != 0u, missing);
+            }
+            // the last two levels and the leaf: {n0, n1, n2, leaf0} {leaf1, leaf2, leaf3, -}, one 32-byte block per walk
+            bsel[j] = idx[j] - first_block_node;
+            const uint4 *bp = kblocks + ((size_t)tt[j] * n_blocks + bsel[j]) * 2;
+            qa[j] = bp[0];
+            qb[j] = bp[1];
+        }
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {
+            const bool r0b = __builtin_amdgcn_inverse_ballot_w64(right_mask(qa[j].x, xkey(qa[j].x), tree[j], idx[j]));
+            c0[j] = r0b ? 1u : 0u;
+            const uint32_t n1 = r0b ? qa[j].z : qa[j].y;
+            const bool r1b = __builtin_amdgcn_inverse_ballot_w64(right_mask(n1, xkey(n1), tree[j], 2u * idx[j] + 1u + c0[j]));
+            c1[j] = r1b ? 1u : 0u;
+            const uint32_t lo = r0b ? qb[j].y : qa[j].w, hi = r0b ? qb[j].z : qb[j].x;
+            leaf[j] = __uint_as_float(r1b ? hi : lo);
+        }
+#endif
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {
+            if (t[j] < num_trees) vals[(size_t)(k % kWkVals) * tv + t[j]] = leaf[j];
+            if (WRITE_LEAF) {
+                if (t[j] < num_trees)
+                    leaf_out[(r0 + k) * (size_t)num_trees + t[j]] =
+                        leaf_orig[(size_t)t[j] * ((size_t)n_blocks * 4) + (size_t)bsel[j] * 4 + 2 * c0[j] + c1[j]];
+            }
+        }
+    };
+    while (k < n && !dead) {
+        const int slot = k % S;
+        {   // the row's keys are in LDS, and its consumer is done with the ring entry
+            int spins = 0;
+            // (the ring entry's previous row, k - kWkVals, belongs to the same consumer: its ((k - kWkVals) / NC)-th row)
+            const uint32_t rows_before = k >= kWkVals ? (uint32_t)((k - kWkVals) / NC + 1) : 0u;
+            while (lds_flag_load(&row_ready[slot]) != (uint32_t)(k + 1) || lds_flag_load(&cdone[k % NC]) < rows_before) {
+                if (++spins > kWkSpinLimit) {
+                    dead = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (dead) break;
+            TAHOE_LDS_ACQUIRE();
+        }
+        if (lds_flag_load(&row_ms[slot]) != 0u)
+            walk_item(std::true_type{}, k, c, slot);
+        else
+            walk_item(std::false_type{}, k, c, slot);
+        TAHOE_LDS_RELEASE();  // values before the flag and the counter; the row's last read precedes them too (in-order LDS)
+        if (lane == 0) {
+            lds_flag_store(&idone[(k % kWkVals) * kWkMaxItems + c], (uint32_t)(k + 1));
+            atomicAdd(&walked[slot], 1u);
+        }
+        c += kWkWalkers;
+        while (c >= nit) {
+            c -= nit;
+            ++k;
+        }
+    }
+    if (dead && lane == 0) atomicOr(error_flag, 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+static long long wk_img_bytes(int lw, int ts) { return ((((1LL << lw) - 1) * ts * 4) + 1023) & ~1023LL; }
+static long long wk_lds(int cols, int num_trees, int lw, int ts, int slots)
+{
+    const long long tv = (num_trees + 3) & ~3;
+    return wk_img_bytes(lw, ts) + (long long)slots * ((cols * 2 + 15) & ~15) + (long long)kWkVals * tv * 4 + (kWkConsumers + 3 * slots + kWkVals * kWkMaxItems) * 4 + 16;
+}
+
+long long wkey_lds_bytes(const tahoe_forest *f)
+{
+    const tahoe_wstate *w = f->wf;
+    return w ? wk_lds(f->p.num_cols, f->p.num_trees, w->s_lw, w->s_ts, w->s_slots) : 0;
+}
+
+void wkey_free(tahoe_wstate *w)
+{
+    if (w->kimg) (void)hipFree(w->kimg);
+    if (w->kblocks) (void)hipFree(w->kblocks);
+    w->kimg = nullptr;
+    w->kblocks = nullptr;
+}
+
+static uint32_t wk_node_word(const InnerNode &nd, uint16_t key)
+{
+    return ((uint32_t)key << 16) | ((nd.meta & 0x7fffu) << 1) | (nd.meta >> 31);
+}
+
+// Builds the image of the tops and the 32-byte bottom blocks when the shape suits the form: rows of 16-byte multiples, feature
+// ids of 15 bits, and LDS for the tops of all trees down to the bottom blocks (levels in between would be walked on float32
+// values from global memory: correct, tested with TAHOE_WSTREAM=1, but slower than the tile form) beside >= kWkLoaders row slots.
+tahoe_status wkey_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner, const std::vector<float> &h_leaf)
+{
+    tahoe_wstate *w = f->wf;
+    if (!w) return TAHOE_OK;
+    const int cols = f->p.num_cols, De = f->depth;
+    const size_t T = (size_t)f->p.num_trees, n_inner = f->n_inner, n_leaf = f->n_leaf;
+    int knob = -1;  // TAHOE_WSTREAM: 0 = never, 1 = whenever it can be built (experiments, tests), unset = the shape rule
+    if (const char *e = getenv("TAHOE_WSTREAM")) knob = atoi(e);
+    if (knob == 0 || cols % 4 != 0 || cols > 3072 || T > ((size_t)1 << 20) || De < 2) return TAHOE_OK;
+    int s_lw = -1, s_ts = 64;  // tree stride of the image: a power of two, 64 .. 1024 (the walk's shifts are immediates)
+    while (s_ts < (int)T) s_ts *= 2;
+    if (s_ts > 1024) return TAHOE_OK;
+    for (int l = std::min(De - 2, 10); l >= 0 && s_lw < 0; --l)
+        if (wk_lds(cols, (int)T, l, s_ts, kWkLoaders) <= f->lds_limit) s_lw = l;
+    if (s_lw < 0) return TAHOE_OK;
+    if (knob != 1 && s_lw != De - 2) return TAHOE_OK;
+    int slots = kWkLoaders;
+    while (slots < 16 && wk_lds(cols, (int)T, s_lw, s_ts, slots + 1) <= f->lds_limit) ++slots;
+    hipError_t e;
+    auto bad = [&](const char *what) { return fail(TAHOE_ERR_HIP, "wkey_build: %s failed: %s", what, hipGetErrorString(e)); };
+    // ---- the key map: [lo, hi] = range of the finite thresholds; their keys from the device ----
+    float lo = 0.f, hi = 0.f;
+    bool any = false;
+    for (const InnerNode &nd : h_inner)
+        if (std::isfinite(nd.thr)) {
+            lo = any ? std::min(lo, nd.thr) : nd.thr;
+            hi = any ? std::max(hi, nd.thr) : nd.thr;
+            any = true;
+        }
+    float scale = (any && hi > lo) ? 65534.0f / (hi - lo) : 0.f;
+    if (!std::isfinite(scale)) scale = 0.f;  // (everything then ties and is decided on the float32 values: slow, correct)
+    std::vector<uint16_t> h_keys(h_inner.size());
+    {
+        std::vector<float> h_thr(h_inner.size());
+        for (size_t i = 0; i < h_inner.size(); ++i) h_thr[i] = h_inner[i].thr;
+        float *d_thr = nullptr;
+        uint16_t *d_keys = nullptr;
+        const size_t nn = std::max<size_t>(h_thr.size(), 1);
+        if ((e = hipMalloc(reinterpret_cast<void **>(&d_thr), nn * sizeof(float))) != hipSuccess) return bad("hipMalloc");
+        if ((e = hipMalloc(reinterpret_cast<void **>(&d_keys), nn * sizeof(uint16_t))) != hipSuccess) {
+            (void)hipFree(d_thr);
+            return bad("hipMalloc");
+        }
+        e = hipMemcpy(d_thr, h_thr.data(), h_thr.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess && !h_thr.empty()) {
+            hipLaunchKernelGGL(wkey_threshold_keys_kernel, dim3((unsigned)((h_thr.size() + 255) / 256)), dim3(256), 0, 0, d_thr, d_keys,
+                               h_thr.size(), lo, scale);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpy(h_keys.data(), d_keys, h_keys.size() * sizeof(uint16_t), hipMemcpyDeviceToHost);
+        (void)hipFree(d_thr);
+        (void)hipFree(d_keys);
+        if (e != hipSuccess) return bad("threshold keys");
+    }
+    const size_t nlv = ((size_t)1 << s_lw) - 1;
+    const size_t img = (size_t)wk_img_bytes(s_lw, s_ts);
+    std::vector<uint32_t> h_img(img / 4, 0u);
+    for (size_t t = 0; t < T; ++t)
+        for (size_t i = 0; i < nlv; ++i) h_img[i * (size_t)s_ts + t] = wk_node_word(h_inner[t * n_inner + i], h_keys[t * n_inner + i]);
+    const size_t n_blocks = (size_t)1 << (De - 2), first = n_blocks - 1;
+    std::vector<uint4> h_kb(T * n_blocks * 2);
+    parallel_for(T, 8, [&](size_t t_lo, size_t t_hi) {
+        for (size_t t = t_lo; t < t_hi; ++t) {
+            const InnerNode *in = &h_inner[t * n_inner];
+            const uint16_t *ky = &h_keys[t * n_inner];
+            for (size_t b = 0; b < n_blocks; ++b) {
+                const size_t r = first + b;
+                uint32_t lv[4];
+                memcpy(lv, &h_leaf[t * n_leaf + 4 * b], 16);
+                h_kb[(t * n_blocks + b) * 2 + 0] = make_uint4(wk_node_word(in[r], ky[r]), wk_node_word(in[2 * r + 1], ky[2 * r + 1]),
+                                                              wk_node_word(in[2 * r + 2], ky[2 * r + 2]), lv[0]);
+                h_kb[(t * n_blocks + b) * 2 + 1] = make_uint4(lv[1], lv[2], lv[3], 0u);
+            }
+        }
+    });
+    auto up = [&](auto **dst, const auto &src) {
+        const size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(src[0]);
+        hipError_t er = hipMalloc(reinterpret_cast<void **>(dst), bytes);
+        if (er != hipSuccess) return er;
+        f->device_bytes += bytes;
+        return src.empty() ? hipSuccess : hipMemcpy(*dst, src.data(), src.size() * sizeof(src[0]), hipMemcpyHostToDevice);
+    };
+    uint32_t *d_img = nullptr;
+    if ((e = up(&d_img, h_img)) != hipSuccess) return bad("kimg");
+    w->kimg = reinterpret_cast<unsigned char *>(d_img);
+    if ((e = up(&w->kblocks, h_kb)) != hipSuccess) return bad("kblocks");
+    w->s_lw = s_lw;
+    w->s_ts = s_ts;
+    w->s_slots = slots;
+    w->s_img_bytes = (int)img;
+    w->key_lo = lo;
+    w->key_scale = scale;
+    w->s_on = true;
+    for (const void *kern : {(const void *)&wkey_kernel<6, false>, (const void *)&wkey_kernel<6, true>, (const void *)&wkey_kernel<7, false>,
+                             (const void *)&wkey_kernel<7, true>, (const void *)&wkey_kernel<8, false>, (const void *)&wkey_kernel<8, true>,
+                             (const void *)&wkey_kernel<9, false>, (const void *)&wkey_kernel<9, true>, (const void *)&wkey_kernel<10, false>,
+                             (const void *)&wkey_kernel<10, true>})
+        if ((e = allow_max_lds(kern, f->lds_limit)) != hipSuccess) return bad("hipFuncSetAttribute");
+    return TAHOE_OK;
+}
+
+tahoe_status wkey_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, const float *data, size_t rows, hipStream_t stream,
+                         const float *sums_in)
+{
+    const tahoe_wstate *w = f->wf;
+    const size_t nch = ((size_t)f->p.num_trees + 63) / 64;
+    const size_t max_per = ((size_t)1 << 30) / nch;  // rows x chunks of one workgroup stay within int
+    size_t grid = std::min<size_t>(rows, (size_t)std::max(f->num_cus, 1));  // one persistent workgroup per CU
+    grid = std::max(grid, (rows + max_per - 1) / max_per);
+    const int lds = (int)wkey_lds_bytes(f);
+    const dim3 block((kWkLoaders + kWkConsumers + kWkWalkers) * 64);
+    auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), block, lds, stream, data, w->kimg, w->kblocks, f->inner, f->leaf_orig, sums, leaf_out,
+                           sums_in, rows, f->p.num_cols, f->p.num_trees, f->depth, w->s_lw, w->s_img_bytes, w->s_slots, f->p.missing,
+                           w->key_lo, w->key_scale, f->error_flag);
+    };
+    switch (w->s_ts) {
+    case 64: leaf_out ? go(wkey_kernel<6, true>) : go(wkey_kernel<6, false>); break;
+    case 128: leaf_out ? go(wkey_kernel<7, true>) : go(wkey_kernel<7, false>); break;
+    case 256: leaf_out ? go(wkey_kernel<8, true>) : go(wkey_kernel<8, false>); break;
+    case 512: leaf_out ? go(wkey_kernel<9, true>) : go(wkey_kernel<9, false>); break;
+    default: leaf_out ? go(wkey_kernel<10, true>) : go(wkey_kernel<10, false>); break;
+    }
+    TAHOE_HIP_TRY(hipGetLastError());
+    return TAHOE_OK;
+}
+
+}  // namespace tahoe

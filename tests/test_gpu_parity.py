@@ -771,16 +771,17 @@ def test_wide_rows_float32_form(env, T, D, C, R, missing_prob):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("T,D,C,R,missing_prob", [
-    (300, 8, 3072, 1003, 0.03),   # K2's shape: five levels of all trees resident, 4 row slots; missing values and NaN
+    (300, 8, 3072, 1003, 0.03),   # K2's shape: six levels of all trees resident, 4 row slots; missing values and NaN
     (300, 8, 3072, 5, 0.0),       # fewer rows than CUs: one-row workgroups
-    (37, 10, 2052, 333, 0.02),    # rows of 8 DMA pieces + a 16-byte tail piece; levels between the LDS tops and the blocks
-    (1200, 9, 1024, 700, 0.01),   # many trees: few resident levels, four levels from the heap in global memory
-    (65, 3, 640, 4097, 0.0),      # depth 3: the whole tree is one bottom block; 65 trees = two chunks, the second one lane
-    (9, 2, 700, 64, 0.05),        # depth 2: the form is unavailable, the tile form serves
+    (37, 10, 2052, 333, 0.02),    # rows of 8 pieces + a 16-byte tail piece (a third chunk with three pieces past the end)
+    (1000, 9, 1024, 700, 0.01),   # many trees: five resident levels, two levels in between on float32 values from global memory
+    (65, 3, 640, 4097, 0.0),      # depth 3: one resident level; 65 trees = two chunks, the second one lane
+    (9, 2, 700, 64, 0.05),        # depth 2: no resident level at all, the whole tree is its one bottom block
 ])
 def test_wide_rows_streaming_form(env, monkeypatch, T, D, C, R, missing_prob):
-    """TAHOE_WSTREAM=1: TILERING on wide rows as the row-streaming kernel (widef.hip, wstream_kernel: tops of all trees resident
-    in LDS, rows through a ring of LDS-DMA slots, lane = tree): leaf indices, sums and continued sums against the oracle."""
+    """TAHOE_WSTREAM=1: TILERING on wide rows as the row-streaming kernel on 16-bit keys whatever the shape (wkey.hip: tops of all
+    trees resident in LDS, rows turned into keys on their way into a ring of LDS slots, lane = tree, equal keys decided on the
+    float32 values): leaf indices, sums and continued sums against the oracle."""
     ta, oracle, torch = env
     monkeypatch.setenv("TAHOE_WSTREAM", "1")
     nodes = ta.synth_forest(T, D, C, seed=950 + T, leaf_prob=0.1 if D > 4 else 0.0)
@@ -789,8 +790,7 @@ def test_wide_rows_streaming_form(env, monkeypatch, T, D, C, R, missing_prob):
         data[3, :5] = [np.inf, -np.inf, -0.0, MISSING + 5e-7, MISSING - 2e-6]
     f = ta.Forest(nodes, T, D, C, missing=MISSING)
     info = f.info()
-    assert (info.stream_slots >= 3 and info.stream_levels == min(info.stream_levels, max(D, 2) - 3)) if D >= 3 else info.stream_slots == 0
-    assert info.stream_levels >= 1 or D <= 3
+    assert info.stream_slots >= 4 and 0 <= info.stream_levels <= max(D, 2) - 2
     assert info.tilering_lds_bytes <= 160 * 1024
     f.set_strategy(ta.STRATEGY_TILERING)
     want, want_leaf = oracle.predict(nodes, T, D, data, MISSING, want_leaf=True, threads=8)
@@ -814,4 +814,43 @@ def test_wide_rows_streaming_form(env, monkeypatch, T, D, C, R, missing_prob):
         assert shifted.data_ptr() % 16 != 0
         assert np.array_equal(bits(f.predict_raw(shifted).cpu().numpy()), bits(want))
         f.check()
+    f.close()
+
+
+@pytest.mark.gpu
+def test_wide_rows_streaming_form_equal_keys(env, monkeypatch):
+    """The 16-bit keys of the row-streaming form decide a compare only when they differ; equal keys fall back to the float32
+    values.  Feature values and thresholds on a coarse grid, nudged by a few ulps either way (and exactly equal: ties go right),
+    make most compares of this case equal-key compares; integer-valued features (pixels) against half-integer thresholds too."""
+    ta, oracle, torch = env
+    monkeypatch.setenv("TAHOE_WSTREAM", "1")
+    T, D, C, R = 150, 8, 1024, 3000
+    rng = np.random.default_rng(77)
+    nodes = ta.synth_forest(T, D, C, seed=970, leaf_prob=0.05)
+    data = ta.synth_data(R, C, seed=971, missing_prob=0.01, missing=MISSING, nan_prob=0.005)
+    grid = lambda a: (np.round(a * 32.0) / 32.0).astype(np.float32)
+    nudge = lambda a: np.nextafter(a, np.float32(np.inf) * rng.choice([-1.0, 1.0], size=a.shape).astype(np.float32)).astype(np.float32)
+    keep = np.isnan(data) | (data == MISSING)
+    coarse = grid(data)
+    mix = rng.random(data.shape)
+    data2 = np.where(mix < 0.4, coarse, np.where(mix < 0.8, nudge(coarse), data)).astype(np.float32)
+    data2[keep] = data[keep]
+    nodes = nodes.copy()
+    thr = grid(nodes["val"])
+    tmix = rng.random(thr.shape)
+    nodes["val"] = np.where(tmix < 0.5, thr, nudge(thr))  # leaf values change too: they are only added
+    data2[:, :8] = np.floor(rng.random((R, 8)) * 256.0).astype(np.float32)  # "pixels"
+    for sel in range(0, nodes.size, 97):  # some thresholds at half-integers, whatever feature they test
+        nodes["val"][sel] = np.float32(rng.integers(0, 256)) + np.float32(0.5)
+    f = ta.Forest(nodes, T, D, C, missing=MISSING)
+    assert f.info().stream_slots >= 4
+    f.set_strategy(ta.STRATEGY_TILERING)
+    want, want_leaf = oracle.predict(nodes, T, D, data2, MISSING, want_leaf=True, threads=8)
+    x = torch.from_numpy(data2).cuda()
+    leaf, sums = f.predict_leaf_idx(x)
+    f.check()
+    assert np.array_equal(bits(leaf.cpu().numpy()), want_leaf)
+    assert np.array_equal(bits(sums.cpu().numpy()), bits(want))
+    f.set_strategy(ta.STRATEGY_DIRECT)
+    assert np.array_equal(bits(f.predict_raw(x).cpu().numpy()), bits(want))
     f.close()

@@ -33,6 +33,7 @@ prop = torch.cuda.get_device_properties(0)
 out = {"note": "rocprofv3 --pmc passes a-f (tools/pmc_script.sh; each pass its own run, no trace domains) over: $SCRIPT; "
                "averages per launch, counters summed over the chip; FETCH_SIZE / WRITE_SIZE in KB",
        "src_hash": bench.kernel_source_hash(), "num_cus": prop.multi_processor_count, "clock_ghz": getattr(prop, 'clock_rate', 2400000) / 1e6,
+       "script": "$SCRIPT",
        "kernels": {k: dict({c: sum(v) / len(v) for c, v in sorted(cs.items())}, launches=len(next(iter(cs.values()))))
                    for k, cs in sorted(kern.items())}}
 json.dump(out, open("gpurun_out/pmc_${tag}.json", "w"), indent=1)
