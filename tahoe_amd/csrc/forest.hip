@@ -1277,7 +1277,9 @@ tahoe_status tahoe_forest_set_strategy(tahoe_forest *f, int strategy)
 tahoe_status tahoe_forest_reserve(tahoe_forest *f, size_t rows)
 {
     if (!f) return fail(TAHOE_ERR_INVALID_ARG, "null forest");
-    return qring_reserve(f, rows);
+    const tahoe_status qs = qring_reserve(f, rows);
+    if (qs != TAHOE_OK) return qs;
+    return widef_reserve(f, rows);  // (the wide-row float32 form's leaf-value workspace, when it streams rows)
 }
 
 tahoe_status tahoe_forest_check(tahoe_forest *f, void *stream)

@@ -170,5 +170,6 @@ int widef_stream_levels(const tahoe_forest *f);     // ... and the levels of all
 tahoe_status widef_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, const float *data, size_t rows, hipStream_t stream,
                           const float *sums_in);
 void widef_destroy(tahoe_forest *f);
+tahoe_status widef_reserve(tahoe_forest *f, size_t rows);
 
 }  // namespace tahoe

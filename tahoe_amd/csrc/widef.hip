@@ -264,6 +264,8 @@ long long widef_lds_bytes(const tahoe_forest *f)
     return w->s_on ? wkey_lds_bytes(f) : wf_lds(f->p.num_cols, w->rt, w->nwalk, w->lw);
 }
 
+tahoe_status widef_reserve(tahoe_forest *f, size_t rows) { return f->wf ? wkey_reserve(f, rows) : TAHOE_OK; }
+
 void widef_destroy(tahoe_forest *f)
 {
     if (!f->wf) return;

@@ -14,6 +14,8 @@ struct tahoe_wstate {
     unsigned char *kimg = nullptr;  // tops of ALL trees, node-major: [2^s_lw - 1][s_ts] u32 key << 16 | fid << 1 | def_left, padded to 1 KiB
     uint4 *kblocks = nullptr;       // [T][2^(De-2)][2]: {n0, n1, n2, leaf0} {leaf1, leaf2, leaf3, -} -- the last two levels in 32 bytes
     int s_lw = 0, s_ts = 0, s_slots = 0, s_img_bytes = 0;
+    float *leafbuf = nullptr;       // workspace [leaf_rows][trees rounded up to 4]: leaf values of a batch, added by wkey_rowsum_kernel
+    size_t leaf_rows = 0;
     float key_lo = 0.f, key_scale = 0.f;  // key(x) = trunc(clamp((x - key_lo) * key_scale, 0, 65534))
     bool s_on = false;              // the launch takes it
 };
@@ -23,6 +25,7 @@ namespace tahoe {
 tahoe_status wkey_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner, const std::vector<float> &h_leaf);
 void wkey_free(tahoe_wstate *w);
 long long wkey_lds_bytes(const tahoe_forest *f);
+tahoe_status wkey_reserve(tahoe_forest *f, size_t rows);  // the leaf-value workspace for batches of up to `rows` rows
 tahoe_status wkey_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, const float *data, size_t rows, hipStream_t stream,
                          const float *sums_in);
 

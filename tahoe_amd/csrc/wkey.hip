@@ -30,10 +30,14 @@
 //     4-KiB chunks in flight per wave), turn them into keys and store them into a ring of S row slots;
 //   * a walker wave takes item (row k, chunk c) = 64 trees of one row: lw levels from LDS, the last two levels and the leaf
 //     from ONE 32-byte block per walk (two gathers; the tile form's 48-byte float32 block takes three), levels in between
-//     (deep trees only) from the heap records with the float32 rule; leaf value into vals[k % 4][t]; the last walker of a row
+//     (deep trees only) from the heap records with the float32 rule; leaf value into the workspace; the last walker of a row
 //     frees its slot;
-//   * four consumer waves, one row each at a time, add the leaf values in tree order as the walkers deliver them: float32
-//     sums bit-identical to predict_on_cpu (BaseTahoeTest.h:462-466).
+//   * the leaf values go to a workspace in global memory, leaf[row][tree] (coalesced 256-byte stores), and a second kernel adds
+//     each row's values in tree order, one lane per row: float32 sums bit-identical to predict_on_cpu (BaseTahoeTest.h:
+//     462-466).  (Consumer waves inside the kernel -- the scheme of the tile kernels -- were tried first: with four rows in LDS
+//     only four 500-term dependent chains can be under way, one lane each, ~19 cycles per add beside 12 busy waves: they cost
+//     0.17 of 0.65 ms whatever their number, profiles/r03/wkey_experiments.txt.  The workspace costs 2 x 4 bytes per (row, tree)
+//     of traffic, most of it absorbed by the 256-MiB Infinity Cache.)
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -45,20 +49,13 @@
 namespace tahoe {
 
 #ifndef TAHOE_WK_LOADERS
-#define TAHOE_WK_LOADERS 4
+#define TAHOE_WK_LOADERS 5
 #endif
 #ifndef TAHOE_WK_WALKERS
-#define TAHOE_WK_WALKERS 8
+#define TAHOE_WK_WALKERS 11
 #endif
-constexpr int kWkLoaders = TAHOE_WK_LOADERS;   // loader waves (= the fewest row slots)
-#ifndef TAHOE_WK_CONSUMERS
-#define TAHOE_WK_CONSUMERS 4
-#endif
-constexpr int kWkConsumers = TAHOE_WK_CONSUMERS;  // consumer waves: consumer q adds rows q, q + NC, ... (one lane per wave: the chain is serial)
-constexpr int kWkVals = 4;                        // rows of leaf values between walkers and consumers (a multiple of kWkConsumers)
-static_assert(kWkVals % kWkConsumers == 0, "a ring entry belongs to one consumer");
-constexpr int kWkMaxItems = 16;                   // items per row (1024 trees in chunks of 64)
-constexpr int kWkWalkers = TAHOE_WK_WALKERS;      // walker waves; 4 + 4 + 8 = 16 waves
+constexpr int kWkLoaders = TAHOE_WK_LOADERS;  // loader waves (= the fewest row slots)
+constexpr int kWkWalkers = TAHOE_WK_WALKERS;  // walker waves; 5 + 11 = 16 waves (4 + 12: 0.622 ms on K2, 5 + 11: 0.609, 2 + 14: 0.627)
 #ifndef TAHOE_WK_CHAINS
 #define TAHOE_WK_CHAINS 2
 #endif
@@ -115,13 +112,13 @@ __device__ __forceinline__ uint32_t wk_descend(uint32_t p, uint64_t right_mask)
 }
 
 template <int TSL, bool WRITE_LEAF>
-__global__ void __launch_bounds__((kWkLoaders + kWkConsumers + kWkWalkers) * 64)
+__global__ void __launch_bounds__((kWkLoaders + kWkWalkers) * 64)
     wkey_kernel(const float *__restrict__ data, const unsigned char *__restrict__ kimg, const uint4 *__restrict__ kblocks,
-                const InnerNode *__restrict__ inner, const uint32_t *__restrict__ leaf_orig, float *sums, uint32_t *__restrict__ leaf_out,
-                const float *sums_in, size_t rows, int cols, int num_trees, int depth, int lw, int img_bytes, int S, float missing,
+                const InnerNode *__restrict__ inner, const uint32_t *__restrict__ leaf_orig, float *__restrict__ leafbuf,
+                uint32_t *__restrict__ leaf_out, size_t rows, int cols, int num_trees, int depth, int lw, int img_bytes, int S, float missing,
                 float key_lo, float key_scale, int *__restrict__ error_flag)
 {
-    constexpr int NL = kWkLoaders, NC = kWkConsumers, NW = kWkLoaders + kWkConsumers + kWkWalkers;
+    constexpr int NL = kWkLoaders, NW = kWkLoaders + kWkWalkers;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -129,12 +126,9 @@ __global__ void __launch_bounds__((kWkLoaders + kWkConsumers + kWkWalkers) * 64)
     const int row_bytes = cols * 4;        // of a float32 row in the batch (a multiple of 16)
     const int slot_bytes = (cols * 2 + 15) & ~15;  // of a row of keys in LDS
     unsigned char *srows = smem + img_bytes;
-    float *vals = reinterpret_cast<float *>(srows + (size_t)S * slot_bytes);
-    uint32_t *cdone = reinterpret_cast<uint32_t *>(vals + (size_t)kWkVals * tv);  // [NC] row groups consumer q has added
-    uint32_t *row_ready = cdone + NC;                                             // [S] row index + 1 whose keys are in the slot
-    uint32_t *walked = row_ready + S;                                               // [S] chunk-walks finished in the slot, monotone
-    uint32_t *row_ms = walked + S;                                                  // [S] != 0: the row in the slot has a missing value
-    uint32_t *idone = row_ms + S;  // [kWkVals][kWkMaxItems] row index + 1 whose leaf values of that item are in the ring entry
+    uint32_t *row_ready = reinterpret_cast<uint32_t *>(srows + (size_t)S * slot_bytes);  // [S] row index + 1 whose keys are in the slot
+    uint32_t *walked = row_ready + S;                                                    // [S] items walked in the slot, monotone
+    uint32_t *row_ms = walked + S;                                                       // [S] != 0: the row has a missing value
     const size_t per = (rows + gridDim.x - 1) / gridDim.x;
     const size_t r0 = (size_t)blockIdx.x * per;
     if (r0 >= rows) return;
@@ -144,8 +138,6 @@ __global__ void __launch_bounds__((kWkLoaders + kWkConsumers + kWkWalkers) * 64)
 
     // ---- the resident tops: the image lies in global memory exactly as in LDS (LDS-DMA: 1 KiB per wave-instruction) ----
     for (int pc = wave; pc < (img_bytes >> 10); pc += NW) wk_dma16(kimg + (size_t)pc * 1024 + lane * 16, smem + (size_t)pc * 1024);
-    if (tid < NC) cdone[tid] = 0u;
-    if (tid < kWkVals * kWkMaxItems) idone[tid] = 0u;
     if (tid < S) {
         row_ready[tid] = 0u;
         walked[tid] = 0u;
@@ -236,78 +228,6 @@ __global__ void __launch_bounds__((kWkLoaders + kWkConsumers + kWkWalkers) * 64)
         return;
     }
 
-    if (wave < NL + NC) {
-        // ================= consumers: consumer q adds rows q, q + NC, ... in tree order, item by item as the walkers deliver them ========
-        // (the 500-term dependent chain of a row takes ~4 k cycles; started only when the whole row was walked, it kept the ring
-        // entry busy for that long behind the row and the walkers waited for it: 0.17 of 0.66 ms.  Now it runs beside the walk of
-        // its own row and ends a quarter of that time after it.)
-        const int q = wave - NL;
-        bool dead = false;
-#ifdef TAHOE_WK_CONS_PRIO
-        __builtin_amdgcn_s_setprio(TAHOE_WK_CONS_PRIO);
-#endif
-        for (int k = q; k < n && !dead; k += NC) {
-            const float *v = vals + (size_t)(k % kWkVals) * tv;
-            float sum = 0.0f;
-            if (lane == 0 && sums_in) sum = sums_in[r0 + k];
-            for (int c = 0; c < nit && !dead; ++c) {
-                int spins = 0;
-                while (lds_flag_load(&idone[(k % kWkVals) * kWkMaxItems + c]) != (uint32_t)(k + 1)) {
-                    if (++spins > kWkSpinLimit) {
-                        dead = true;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                if (dead) break;
-                TAHOE_LDS_ACQUIRE();  // the values are read after the flag
-                if (lane == 0 && !WK_NO_ADD) {
-                    int t = c * (64 * kWkChains);
-                    const int t_end = min(num_trees, t + 64 * kWkChains);
-                    if (t + 16 <= t_end) {  // tree order; the next sixteen values are read while these sixteen are added
-                        float4 p0 = *reinterpret_cast<const float4 *>(v + t), p1 = *reinterpret_cast<const float4 *>(v + t + 4);
-                        float4 p2 = *reinterpret_cast<const float4 *>(v + t + 8), p3 = *reinterpret_cast<const float4 *>(v + t + 12);
-                        for (;;) {
-                            const bool more = t + 32 <= t_end;
-                            const float *nx = v + (more ? t + 16 : t);
-                            const float4 n0 = *reinterpret_cast<const float4 *>(nx), n1 = *reinterpret_cast<const float4 *>(nx + 4);
-                            const float4 n2 = *reinterpret_cast<const float4 *>(nx + 8), n3 = *reinterpret_cast<const float4 *>(nx + 12);
-                            sum += p0.x;
-                            sum += p0.y;
-                            sum += p0.z;
-                            sum += p0.w;
-                            sum += p1.x;
-                            sum += p1.y;
-                            sum += p1.z;
-                            sum += p1.w;
-                            sum += p2.x;
-                            sum += p2.y;
-                            sum += p2.z;
-                            sum += p2.w;
-                            sum += p3.x;
-                            sum += p3.y;
-                            sum += p3.z;
-                            sum += p3.w;
-                            t += 16;
-                            if (!more) break;
-                            p0 = n0;
-                            p1 = n1;
-                            p2 = n2;
-                            p3 = n3;
-                        }
-                    }
-                    for (; t < t_end; ++t) sum += v[t];
-                }
-            }
-            if (dead) break;
-            if (lane == 0 && sums && !WK_NO_ADD) sums[r0 + k] = sum;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the values have been read
-            if (lane == 0) lds_flag_store(&cdone[q], (uint32_t)(k / NC + 1));
-        }
-        if (dead && lane == 0) atomicOr(error_flag, 1);
-        return;
-    }
-
     // ================= walkers: item = (row k, kWkChains chunks of 64 trees); chain j of a lane = tree (c * KC + j) * 64 + lane =========
     constexpr int KC = kWkChains;
     const size_t n_inner = ((size_t)1 << depth) - 1;
@@ -319,7 +239,7 @@ __global__ void __launch_bounds__((kWkLoaders + kWkConsumers + kWkWalkers) * 64)
     }
     const uint32_t xbase0 = (uint32_t)img_bytes;
     bool dead = false;
-    int k = 0, c = wave - NL - NC;
+    int k = 0, c = wave - NL;
     while (c >= nit) {
         c -= nit;
         ++k;
@@ -424,7 +344,7 @@ __global__ void __launch_bounds__((kWkLoaders + kWkConsumers + kWkWalkers) * 64)
 #endif
 #pragma unroll
         for (int j = 0; j < KC; ++j) {
-            if (t[j] < num_trees) vals[(size_t)(k % kWkVals) * tv + t[j]] = leaf[j];
+            if (leafbuf && t[j] < num_trees) leafbuf[(r0 + k) * (size_t)tv + t[j]] = leaf[j];
             if (WRITE_LEAF) {
                 if (t[j] < num_trees)
                     leaf_out[(r0 + k) * (size_t)num_trees + t[j]] =
@@ -434,11 +354,9 @@ __global__ void __launch_bounds__((kWkLoaders + kWkConsumers + kWkWalkers) * 64)
     };
     while (k < n && !dead) {
         const int slot = k % S;
-        {   // the row's keys are in LDS, and its consumer is done with the ring entry
+        {   // the row's keys are in LDS
             int spins = 0;
-            // (the ring entry's previous row, k - kWkVals, belongs to the same consumer: its ((k - kWkVals) / NC)-th row)
-            const uint32_t rows_before = k >= kWkVals ? (uint32_t)((k - kWkVals) / NC + 1) : 0u;
-            while (lds_flag_load(&row_ready[slot]) != (uint32_t)(k + 1) || lds_flag_load(&cdone[k % NC]) < rows_before) {
+            while (lds_flag_load(&row_ready[slot]) != (uint32_t)(k + 1)) {
                 if (++spins > kWkSpinLimit) {
                     dead = true;
                     break;
@@ -452,11 +370,8 @@ __global__ void __launch_bounds__((kWkLoaders + kWkConsumers + kWkWalkers) * 64)
             walk_item(std::true_type{}, k, c, slot);
         else
             walk_item(std::false_type{}, k, c, slot);
-        TAHOE_LDS_RELEASE();  // values before the flag and the counter; the row's last read precedes them too (in-order LDS)
-        if (lane == 0) {
-            lds_flag_store(&idone[(k % kWkVals) * kWkMaxItems + c], (uint32_t)(k + 1));
-            atomicAdd(&walked[slot], 1u);
-        }
+        TAHOE_LDS_RELEASE();  // the row's last read precedes the counter (in-order LDS)
+        if (lane == 0) atomicAdd(&walked[slot], 1u);
         c += kWkWalkers;
         while (c >= nit) {
             c -= nit;
@@ -466,13 +381,39 @@ __global__ void __launch_bounds__((kWkLoaders + kWkConsumers + kWkWalkers) * 64)
     if (dead && lane == 0) atomicOr(error_flag, 1);
 }
 
+// The ordered sum: lane = row, the row's leaf values in tree order (float4 reads: a lane sweeps its own 128-byte lines, so
+// they stay in L1 between its loads), continuing sums_in where given (sums_in may alias sums).
+__global__ void __launch_bounds__(256) wkey_rowsum_kernel(const float *__restrict__ leafbuf, const float *sums_in, float *sums, size_t rows,
+                                                          int num_trees, int tv)
+{
+    const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    const float *v = leafbuf + row * (size_t)tv;
+    float sum = sums_in ? sums_in[row] : 0.0f;
+    int t = 0;
+#if !WK_NO_ADD
+    for (; t + 8 <= num_trees; t += 8) {
+        const float4 p = *reinterpret_cast<const float4 *>(v + t), q = *reinterpret_cast<const float4 *>(v + t + 4);
+        sum += p.x;
+        sum += p.y;
+        sum += p.z;
+        sum += p.w;
+        sum += q.x;
+        sum += q.y;
+        sum += q.z;
+        sum += q.w;
+    }
+    for (; t < num_trees; ++t) sum += v[t];
+#endif
+    sums[row] = sum;
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 static long long wk_img_bytes(int lw, int ts) { return ((((1LL << lw) - 1) * ts * 4) + 1023) & ~1023LL; }
 static long long wk_lds(int cols, int num_trees, int lw, int ts, int slots)
 {
-    const long long tv = (num_trees + 3) & ~3;
-    return wk_img_bytes(lw, ts) + (long long)slots * ((cols * 2 + 15) & ~15) + (long long)kWkVals * tv * 4 + (kWkConsumers + 3 * slots + kWkVals * kWkMaxItems) * 4 + 16;
+    return wk_img_bytes(lw, ts) + (long long)slots * ((cols * 2 + 15) & ~15) + 3LL * slots * 4 + 16;
 }
 
 long long wkey_lds_bytes(const tahoe_forest *f)
@@ -485,6 +426,9 @@ void wkey_free(tahoe_wstate *w)
 {
     if (w->kimg) (void)hipFree(w->kimg);
     if (w->kblocks) (void)hipFree(w->kblocks);
+    if (w->leafbuf) (void)hipFree(w->leafbuf);
+    w->leafbuf = nullptr;
+    w->leaf_rows = 0;
     w->kimg = nullptr;
     w->kblocks = nullptr;
 }
@@ -512,7 +456,11 @@ tahoe_status wkey_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner, 
     for (int l = std::min(De - 2, 10); l >= 0 && s_lw < 0; --l)
         if (wk_lds(cols, (int)T, l, s_ts, kWkLoaders) <= f->lds_limit) s_lw = l;
     if (s_lw < 0) return TAHOE_OK;
-    if (knob != 1 && s_lw != De - 2) return TAHOE_OK;
+    // The shape rule (tools/selector_wide.py, profiles/r03/selector_wide.json: the faster form of TILERING on 7 of the 8 shapes
+    // it can serve, 3 % behind on the eighth): every level above the bottom blocks resident, and at most a tree per three
+    // features -- more trees per row than that and the tile form's staged tops, shared by the rows of a tile, cost less than
+    // this form's two gathers per walk.
+    if (knob != 1 && (s_lw != De - 2 || 3 * T > (size_t)cols)) return TAHOE_OK;
     int slots = kWkLoaders;
     while (slots < 16 && wk_lds(cols, (int)T, s_lw, s_ts, slots + 1) <= f->lds_limit) ++slots;
     hipError_t e;
@@ -598,20 +546,44 @@ tahoe_status wkey_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner, 
     return TAHOE_OK;
 }
 
+// The leaf-value workspace, [rows][trees rounded up to 4] floats, grow-only like the quantised forms' (tahoe_forest_reserve).
+tahoe_status wkey_reserve(tahoe_forest *f, size_t rows)
+{
+    tahoe_wstate *w = f->wf;
+    if (!w || !w->s_on || rows <= w->leaf_rows) return TAHOE_OK;
+    const size_t tv = ((size_t)f->p.num_trees + 3) & ~(size_t)3;
+    if (w->leafbuf) {
+        TAHOE_HIP_TRY(hipDeviceSynchronize());  // a previous launch may still use the old buffer
+        TAHOE_HIP_TRY(hipFree(w->leafbuf));
+        f->device_bytes -= w->leaf_rows * tv * sizeof(float);
+        w->leafbuf = nullptr;
+        w->leaf_rows = 0;
+    }
+    TAHOE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&w->leafbuf), rows * tv * sizeof(float)));
+    w->leaf_rows = rows;
+    f->device_bytes += rows * tv * sizeof(float);
+    return TAHOE_OK;
+}
+
 tahoe_status wkey_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, const float *data, size_t rows, hipStream_t stream,
                          const float *sums_in)
 {
-    const tahoe_wstate *w = f->wf;
+    tahoe_wstate *w = f->wf;
+    if (sums) {
+        const tahoe_status rs = wkey_reserve(f, rows);
+        if (rs != TAHOE_OK) return rs;
+    }
     const size_t nch = ((size_t)f->p.num_trees + 63) / 64;
     const size_t max_per = ((size_t)1 << 30) / nch;  // rows x chunks of one workgroup stay within int
     size_t grid = std::min<size_t>(rows, (size_t)std::max(f->num_cus, 1));  // one persistent workgroup per CU
     grid = std::max(grid, (rows + max_per - 1) / max_per);
     const int lds = (int)wkey_lds_bytes(f);
-    const dim3 block((kWkLoaders + kWkConsumers + kWkWalkers) * 64);
+    const dim3 block((kWkLoaders + kWkWalkers) * 64);
+    float *leafbuf = sums ? w->leafbuf : nullptr;
     auto go = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), block, lds, stream, data, w->kimg, w->kblocks, f->inner, f->leaf_orig, sums, leaf_out,
-                           sums_in, rows, f->p.num_cols, f->p.num_trees, f->depth, w->s_lw, w->s_img_bytes, w->s_slots, f->p.missing,
-                           w->key_lo, w->key_scale, f->error_flag);
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), block, lds, stream, data, w->kimg, w->kblocks, f->inner, f->leaf_orig, leafbuf, leaf_out,
+                           rows, f->p.num_cols, f->p.num_trees, f->depth, w->s_lw, w->s_img_bytes, w->s_slots, f->p.missing, w->key_lo,
+                           w->key_scale, f->error_flag);
     };
     switch (w->s_ts) {
     case 64: leaf_out ? go(wkey_kernel<6, true>) : go(wkey_kernel<6, false>); break;
@@ -621,6 +593,12 @@ tahoe_status wkey_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, const
     default: leaf_out ? go(wkey_kernel<10, true>) : go(wkey_kernel<10, false>); break;
     }
     TAHOE_HIP_TRY(hipGetLastError());
+    if (sums) {
+        const int tv = (f->p.num_trees + 3) & ~3;
+        hipLaunchKernelGGL(wkey_rowsum_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, leafbuf, sums_in, sums, rows,
+                           f->p.num_trees, tv);
+        TAHOE_HIP_TRY(hipGetLastError());
+    }
     return TAHOE_OK;
 }
 
