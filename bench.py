@@ -41,7 +41,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 MISSING = -999.0
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r03")
 
 
 def algorithmic_bytes_per_sample(T, depth, cols, bits_bytes):
@@ -81,7 +81,7 @@ def load_profile(name):
 def physical_ceilings(prof, walk_ms, quant_ms, rows, cols):
     """Per-kernel fractions of the ceilings that physically bind, from the PMC counters of the
     profiled run (ratios inside that run) next to the live kernel times of this one."""
-    out = {"source": "profiles/r02/pmc_k3.json", "src_hash": prof["src_hash"]}
+    out = {"source": "profiles/r03/pmc_k3.json", "src_hash": prof["src_hash"]}
     for key, kname in (("walk", "qring"), ("quantise", "quantize")):
         parts = [v for n, v in prof["kernels"].items() if kname in n and "bucket_index" not in n]
         if not parts:
@@ -323,7 +323,7 @@ def main():
     # and trees this launch processes, divided by the measured kernel time of the WHOLE step (quantise pre-pass + walk).
     # Those bytes are mostly served from LDS (2-byte rank codes, 4-byte nodes), which is the point of the layout, so the
     # figure exceeds the HBM peak: it says how the step compares with the reference's byte model run at HBM speed, not
-    # that HBM moves that much.  What physically binds is under "physical" (PMC counters of profiles/r02) and
+    # that HBM moves that much.  What physically binds is under "physical" (PMC counters of profiles/r03) and
     # "hbm_frac_measured" (counter bytes over the same time, <= 1).
     strategy_name = ta.STRATEGY_NAMES.get(forest.get_strategy(my_rows), "?")
     b_alg = algorithmic_bytes_per_sample(my_T, D, C, info.bits_bytes) * my_rows
@@ -352,7 +352,7 @@ def main():
                       "the visits are served from LDS -- see hbm_frac_measured and physical for the ceilings that bind",
         "traffic": traffic,
         "traffic_unit": "HBM-side bytes per step, FETCH_SIZE + WRITE_SIZE of both kernels, raw counters of the rocprofv3 --pmc "
-                        "passes in profiles/r02/pmc_k3.json (null when that profile was not taken with these kernel sources)",
+                        "passes in profiles/r03/pmc_k3.json (null when that profile was not taken with these kernel sources)",
         "hbm_frac_measured": round(traffic / (step_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None,
         "kernel_ms_avg": round(step_kernel_ms, 4),
         "kernel_ms_source": "hipEvents on the launch stream, inside the library" if have_times else "wall time of the step",

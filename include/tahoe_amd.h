@@ -106,17 +106,30 @@ enum {
                                     one 32-byte block per walk; two barriers per round of 4 trees */
     TAHOE_STRATEGY_TILERING = 4, /* TILEBLOCK's data path with decoupled waves: walker waves with
                                     private tops, no barrier in the tree loop, one consumer wave adds
-                                    leaf values in tree order through an LDS ring.  num_cols > 512: the
-                                    wide-row form -- 32- / 16- / 8-row float32 tiles staged as they lie in
-                                    memory, 2 / 4 / 8 trees per wave, 48-byte bottom blocks; AUTO's choice
-                                    there when 2 x trees x depth < 13 x num_cols (no quantise pass) */
+                                    leaf values in tree order through an LDS ring.  num_cols > 512, two
+                                    forms picked at create: (a) tiles -- 32- / 16- / 8-row float32 tiles
+                                    staged as they lie in memory, 2 / 4 / 8 trees per wave, 48-byte bottom
+                                    blocks; (b) row streaming on 16-bit keys (num_cols <= 3072 and a multiple
+                                    of 4, at most a tree per three features and 1024 trees, LDS for every
+                                    level above the last two of ALL trees): one persistent workgroup per CU,
+                                    rows turned into monotone 16-bit keys on their way into a ring of LDS
+                                    slots, lane = tree, equal keys decided on the float32 values, leaf values
+                                    through a workspace (tahoe_forest_reserve) and added in tree order by a
+                                    summer wave.  AUTO's choice for wide rows when 2 x trees x depth <
+                                    13 x num_cols (10 x where QRING walks three trees per lane): no quantise
+                                    pass */
     TAHOE_STRATEGY_QRING = 5     /* TILERING on rank-quantised data: features and thresholds become
-                                    exact 16-bit ranks (a per-predict quantise pass), 128-row u16 tile,
-                                    4-byte nodes, up to 15 walker waves x 2 chains; rows too wide for that
-                                    tile use 64- / 32- / 16-row tiles with several trees per wave; forests
-                                    with more than 32767 distinct thresholds on a feature are walked in
-                                    groups of consecutive trees with chained float32 sums (still the one
-                                    sequential sum); unavailable only if a single tree exceeds that */
+                                    exact 16-bit ranks (a per-predict quantise pass), 4-byte nodes.
+                                    num_cols <= 256: tiles of three (or two) 64-row regions = 192 (128)
+                                    rows, 14 walker waves x 3 chains (15 x 2), a batch walked as whole
+                                    waves of 192-row tiles + a remainder of 128-row tiles; small batches
+                                    give every tile to several workgroups, each a slice of the trees, and
+                                    an ordered-sum kernel adds the leaf values in tree order (SPLIT).
+                                    Wider rows: 128-row tiles, or 64- / 32- / 16-row tiles with several
+                                    trees per wave.  Forests with more than 32767 distinct thresholds on a
+                                    feature are walked in groups of consecutive trees with chained float32
+                                    sums (still the one sequential sum); unavailable only if a single tree
+                                    exceeds that */
 };
 /* On a sparse handle (tahoe_sparse_forest_create): DIRECT = nodes and features from global memory,
  * ROWTILE = 64-row float32 tile in LDS, TILEBLOCK = tile + the first 512 nodes of each tree (breadth-first)

@@ -14,7 +14,7 @@ struct tahoe_wstate {
     unsigned char *kimg = nullptr;  // tops of ALL trees, node-major: [2^s_lw - 1][s_ts] u32 key << 16 | fid << 1 | def_left, padded to 1 KiB
     uint4 *kblocks = nullptr;       // [T][2^(De-2)][2]: {n0, n1, n2, leaf0} {leaf1, leaf2, leaf3, -} -- the last two levels in 32 bytes
     int s_lw = 0, s_ts = 0, s_slots = 0, s_img_bytes = 0;
-    float *leafbuf = nullptr;       // workspace [leaf_rows][trees rounded up to 4]: leaf values of a batch, added by wkey_rowsum_kernel
+    float *leafbuf = nullptr;       // workspace [leaf_rows][trees rounded up to 32]: leaf values of a batch, added in tree order by the kernel's summer wave
     size_t leaf_rows = 0;
     float key_lo = 0.f, key_scale = 0.f;  // key(x) = trunc(clamp((x - key_lo) * key_scale, 0, 65534))
     bool s_on = false;              // the launch takes it

@@ -32,9 +32,9 @@
 //     from ONE 32-byte block per walk (two gathers; the tile form's 48-byte float32 block takes three), levels in between
 //     (deep trees only) from the heap records with the float32 rule; leaf value into the workspace; the last walker of a row
 //     frees its slot;
-//   * the leaf values go to a workspace in global memory, leaf[row][tree] (coalesced 256-byte stores), and a second kernel adds
-//     each row's values in tree order, one lane per row: float32 sums bit-identical to predict_on_cpu (BaseTahoeTest.h:
-//     462-466).  (Consumer waves inside the kernel -- the scheme of the tile kernels -- were tried first: with four rows in LDS
+//   * the leaf values go to a workspace in global memory, leaf[row][tree] (coalesced 256-byte stores), and a summer wave of the
+//     same workgroup adds them 64 rows at a time, one lane per row, in tree order: float32 sums bit-identical to predict_on_cpu
+//     (BaseTahoeTest.h:462-466).  (Consumer waves inside the kernel -- the scheme of the tile kernels -- were tried first: with four rows in LDS
 //     only four 500-term dependent chains can be under way, one lane each, ~19 cycles per add beside 12 busy waves: they cost
 //     0.17 of 0.65 ms whatever their number, profiles/r03/wkey_experiments.txt.  The workspace costs 2 x 4 bytes per (row, tree)
 //     of traffic, most of it absorbed by the 256-MiB Infinity Cache.)
@@ -49,13 +49,14 @@
 namespace tahoe {
 
 #ifndef TAHOE_WK_LOADERS
-#define TAHOE_WK_LOADERS 5
+#define TAHOE_WK_LOADERS 4
 #endif
 #ifndef TAHOE_WK_WALKERS
 #define TAHOE_WK_WALKERS 11
 #endif
 constexpr int kWkLoaders = TAHOE_WK_LOADERS;  // loader waves (= the fewest row slots)
-constexpr int kWkWalkers = TAHOE_WK_WALKERS;  // walker waves; 5 + 11 = 16 waves (4 + 12: 0.622 ms on K2, 5 + 11: 0.609, 2 + 14: 0.627)
+constexpr int kWkWalkers = TAHOE_WK_WALKERS;  // walker waves; 4 loaders + 1 summer + 11 walkers = 16 waves (K2: 0.592 ms; 5 + 10: 0.604, 3 + 12: 0.621)
+constexpr int kWkSumRows = 64;                // rows the summer wave adds at once, one lane each
 #ifndef TAHOE_WK_CHAINS
 #define TAHOE_WK_CHAINS 2
 #endif
@@ -112,23 +113,24 @@ __device__ __forceinline__ uint32_t wk_descend(uint32_t p, uint64_t right_mask)
 }
 
 template <int TSL, bool WRITE_LEAF>
-__global__ void __launch_bounds__((kWkLoaders + kWkWalkers) * 64)
+__global__ void __launch_bounds__((kWkLoaders + 1 + kWkWalkers) * 64)
     wkey_kernel(const float *__restrict__ data, const unsigned char *__restrict__ kimg, const uint4 *__restrict__ kblocks,
                 const InnerNode *__restrict__ inner, const uint32_t *__restrict__ leaf_orig, float *__restrict__ leafbuf,
-                uint32_t *__restrict__ leaf_out, size_t rows, int cols, int num_trees, int depth, int lw, int img_bytes, int S, float missing,
+                float *sums, const float *sums_in, uint32_t *__restrict__ leaf_out, size_t rows, int cols, int num_trees, int depth, int lw, int img_bytes, int S, float missing,
                 float key_lo, float key_scale, int *__restrict__ error_flag)
 {
-    constexpr int NL = kWkLoaders, NW = kWkLoaders + kWkWalkers;
+    constexpr int NL = kWkLoaders, NW = kWkLoaders + 1 + kWkWalkers;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tv = (num_trees + 3) & ~3;
+    const int tv = (num_trees + 31) & ~31;  // floats per row of the workspace: whole 128-byte lines, no line shared by two rows
     const int row_bytes = cols * 4;        // of a float32 row in the batch (a multiple of 16)
     const int slot_bytes = (cols * 2 + 15) & ~15;  // of a row of keys in LDS
     unsigned char *srows = smem + img_bytes;
     uint32_t *row_ready = reinterpret_cast<uint32_t *>(srows + (size_t)S * slot_bytes);  // [S] row index + 1 whose keys are in the slot
     uint32_t *walked = row_ready + S;                                                    // [S] items walked in the slot, monotone
     uint32_t *row_ms = walked + S;                                                       // [S] != 0: the row has a missing value
+    uint32_t *prog = row_ms + S;  // [kWkWalkers] items of walker w whose leaf values have reached the workspace (stores complete)
     const size_t per = (rows + gridDim.x - 1) / gridDim.x;
     const size_t r0 = (size_t)blockIdx.x * per;
     if (r0 >= rows) return;
@@ -138,6 +140,7 @@ __global__ void __launch_bounds__((kWkLoaders + kWkWalkers) * 64)
 
     // ---- the resident tops: the image lies in global memory exactly as in LDS (LDS-DMA: 1 KiB per wave-instruction) ----
     for (int pc = wave; pc < (img_bytes >> 10); pc += NW) wk_dma16(kimg + (size_t)pc * 1024 + lane * 16, smem + (size_t)pc * 1024);
+    if (tid < kWkWalkers) prog[tid] = 0u;
     if (tid < S) {
         row_ready[tid] = 0u;
         walked[tid] = 0u;
@@ -228,6 +231,55 @@ __global__ void __launch_bounds__((kWkLoaders + kWkWalkers) * 64)
         return;
     }
 
+    if (wave == NL) {
+        // ================= summer: rows [64 j, 64 j + 64) of this workgroup, one lane each, once all their leaf values are in the
+        // workspace: the row's values in tree order, float32 -- the sequential sum of predict_on_cpu, 64 rows per add instruction
+        // (consumer waves fed through LDS can only have as many chains under way as there are rows in LDS: four).  A lane sweeps
+        // whole 128-byte lines that no other row shares and that this CU has not read before: nothing stale can sit in L1.
+        if (!leafbuf) return;
+        bool dead = false;
+        for (int g0 = 0; g0 < n && !dead; g0 += kWkSumRows) {
+            const int g1 = min(n, g0 + kWkSumRows);
+            const int need_items = g1 * nit;  // items 0 .. need_items - 1 stored; item i is walker (i % NWALK)'s (i / NWALK)-th
+            const int w = min(lane, kWkWalkers - 1);
+            const uint32_t need = need_items > w ? (uint32_t)((need_items - w + kWkWalkers - 1) / kWkWalkers) : 0u;
+            int spins = 0;
+            for (;;) {
+                const bool ok = lds_flag_load(&prog[w]) >= need;
+                if (__ballot(ok) == ~0ull) break;
+                if (++spins > kWkSpinLimit) {
+                    dead = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (dead) break;
+            const int k = g0 + lane;
+            if (k < g1) {
+                const float *v = leafbuf + (r0 + k) * (size_t)tv;
+                float sum = sums_in ? sums_in[r0 + k] : 0.0f;
+                int t = 0;
+#if !WK_NO_ADD
+                for (; t + 8 <= num_trees; t += 8) {
+                    const float4 p = *reinterpret_cast<const float4 *>(v + t), q = *reinterpret_cast<const float4 *>(v + t + 4);
+                    sum += p.x;
+                    sum += p.y;
+                    sum += p.z;
+                    sum += p.w;
+                    sum += q.x;
+                    sum += q.y;
+                    sum += q.z;
+                    sum += q.w;
+                }
+                for (; t < num_trees; ++t) sum += v[t];
+#endif
+                sums[r0 + k] = sum;
+            }
+        }
+        if (dead && lane == 0) atomicOr(error_flag, 1);
+        return;
+    }
+
     // ================= walkers: item = (row k, kWkChains chunks of 64 trees); chain j of a lane = tree (c * KC + j) * 64 + lane =========
     constexpr int KC = kWkChains;
     const size_t n_inner = ((size_t)1 << depth) - 1;
@@ -239,7 +291,9 @@ __global__ void __launch_bounds__((kWkLoaders + kWkWalkers) * 64)
     }
     const uint32_t xbase0 = (uint32_t)img_bytes;
     bool dead = false;
-    int k = 0, c = wave - NL;
+    const int wid = wave - NL - 1;  // walker index
+    int k = 0, c = wid;
+    uint32_t items_done = 0;  // items of this walker whose leaf values are stored (counted once their stores are complete)
     while (c >= nit) {
         c -= nit;
         ++k;
@@ -366,46 +420,28 @@ __global__ void __launch_bounds__((kWkLoaders + kWkWalkers) * 64)
             if (dead) break;
             TAHOE_LDS_ACQUIRE();
         }
+        if (leafbuf && items_done != 0u) {  // the previous item's leaf values have reached the workspace: tell the summer
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) lds_flag_store(&prog[wid], items_done);
+        }
         if (lds_flag_load(&row_ms[slot]) != 0u)
             walk_item(std::true_type{}, k, c, slot);
         else
             walk_item(std::false_type{}, k, c, slot);
         TAHOE_LDS_RELEASE();  // the row's last read precedes the counter (in-order LDS)
         if (lane == 0) atomicAdd(&walked[slot], 1u);
+        ++items_done;
         c += kWkWalkers;
         while (c >= nit) {
             c -= nit;
             ++k;
         }
     }
-    if (dead && lane == 0) atomicOr(error_flag, 1);
-}
-
-// The ordered sum: lane = row, the row's leaf values in tree order (float4 reads: a lane sweeps its own 128-byte lines, so
-// they stay in L1 between its loads), continuing sums_in where given (sums_in may alias sums).
-__global__ void __launch_bounds__(256) wkey_rowsum_kernel(const float *__restrict__ leafbuf, const float *sums_in, float *sums, size_t rows,
-                                                          int num_trees, int tv)
-{
-    const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= rows) return;
-    const float *v = leafbuf + row * (size_t)tv;
-    float sum = sums_in ? sums_in[row] : 0.0f;
-    int t = 0;
-#if !WK_NO_ADD
-    for (; t + 8 <= num_trees; t += 8) {
-        const float4 p = *reinterpret_cast<const float4 *>(v + t), q = *reinterpret_cast<const float4 *>(v + t + 4);
-        sum += p.x;
-        sum += p.y;
-        sum += p.z;
-        sum += p.w;
-        sum += q.x;
-        sum += q.y;
-        sum += q.z;
-        sum += q.w;
+    if (leafbuf) {  // the last item's leaf values; a walker that never had an item reports what the summer expects of it: nothing
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) lds_flag_store(&prog[wid], items_done);
     }
-    for (; t < num_trees; ++t) sum += v[t];
-#endif
-    sums[row] = sum;
+    if (dead && lane == 0) atomicOr(error_flag, 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -413,7 +449,7 @@ __global__ void __launch_bounds__(256) wkey_rowsum_kernel(const float *__restric
 static long long wk_img_bytes(int lw, int ts) { return ((((1LL << lw) - 1) * ts * 4) + 1023) & ~1023LL; }
 static long long wk_lds(int cols, int num_trees, int lw, int ts, int slots)
 {
-    return wk_img_bytes(lw, ts) + (long long)slots * ((cols * 2 + 15) & ~15) + 3LL * slots * 4 + 16;
+    return wk_img_bytes(lw, ts) + (long long)slots * ((cols * 2 + 15) & ~15) + (3LL * slots + kWkWalkers) * 4 + 16;
 }
 
 long long wkey_lds_bytes(const tahoe_forest *f)
@@ -546,12 +582,12 @@ tahoe_status wkey_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner, 
     return TAHOE_OK;
 }
 
-// The leaf-value workspace, [rows][trees rounded up to 4] floats, grow-only like the quantised forms' (tahoe_forest_reserve).
+// The leaf-value workspace, [rows][trees rounded up to 32] floats (whole 128-byte lines per row), grow-only like the quantised forms' (tahoe_forest_reserve).
 tahoe_status wkey_reserve(tahoe_forest *f, size_t rows)
 {
     tahoe_wstate *w = f->wf;
     if (!w || !w->s_on || rows <= w->leaf_rows) return TAHOE_OK;
-    const size_t tv = ((size_t)f->p.num_trees + 3) & ~(size_t)3;
+    const size_t tv = ((size_t)f->p.num_trees + 31) & ~(size_t)31;
     if (w->leafbuf) {
         TAHOE_HIP_TRY(hipDeviceSynchronize());  // a previous launch may still use the old buffer
         TAHOE_HIP_TRY(hipFree(w->leafbuf));
@@ -578,11 +614,11 @@ tahoe_status wkey_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, const
     size_t grid = std::min<size_t>(rows, (size_t)std::max(f->num_cus, 1));  // one persistent workgroup per CU
     grid = std::max(grid, (rows + max_per - 1) / max_per);
     const int lds = (int)wkey_lds_bytes(f);
-    const dim3 block((kWkLoaders + kWkWalkers) * 64);
+    const dim3 block((kWkLoaders + 1 + kWkWalkers) * 64);
     float *leafbuf = sums ? w->leafbuf : nullptr;
     auto go = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), block, lds, stream, data, w->kimg, w->kblocks, f->inner, f->leaf_orig, leafbuf, leaf_out,
-                           rows, f->p.num_cols, f->p.num_trees, f->depth, w->s_lw, w->s_img_bytes, w->s_slots, f->p.missing, w->key_lo,
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), block, lds, stream, data, w->kimg, w->kblocks, f->inner, f->leaf_orig, leafbuf, sums, sums_in,
+                           leaf_out, rows, f->p.num_cols, f->p.num_trees, f->depth, w->s_lw, w->s_img_bytes, w->s_slots, f->p.missing, w->key_lo,
                            w->key_scale, f->error_flag);
     };
     switch (w->s_ts) {
@@ -593,12 +629,6 @@ tahoe_status wkey_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, const
     default: leaf_out ? go(wkey_kernel<10, true>) : go(wkey_kernel<10, false>); break;
     }
     TAHOE_HIP_TRY(hipGetLastError());
-    if (sums) {
-        const int tv = (f->p.num_trees + 3) & ~3;
-        hipLaunchKernelGGL(wkey_rowsum_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, leafbuf, sums_in, sums, rows,
-                           f->p.num_trees, tv);
-        TAHOE_HIP_TRY(hipGetLastError());
-    }
     return TAHOE_OK;
 }
 

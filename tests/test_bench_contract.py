@@ -49,14 +49,14 @@ def test_bench_source_keeps_the_oracle_out_of_the_timed_regions():
 
 
 def test_committed_pmc_profile_belongs_to_these_kernel_sources():
-    """roofline.traffic / roofline.physical come from profiles/r02/pmc_k3.json only while its stamp matches the device
+    """roofline.traffic / roofline.physical come from profiles/r03/pmc_k3.json only while its stamp matches the device
     sources in the tree (bench.kernel_source_hash); a kernel edit without a fresh tools/pmc.sh run turns this red."""
     import sys
 
     sys.path.insert(0, ROOT)
     import bench
 
-    prof = json.load(open(os.path.join(ROOT, "profiles", "r02", "pmc_k3.json")))
+    prof = json.load(open(os.path.join(ROOT, "profiles", "r03", "pmc_k3.json")))
     assert prof["src_hash"] == bench.kernel_source_hash()
     phys = bench.physical_ceilings(prof, 3.7, 0.77, 1_000_000, 256)
     for kern in ("walk", "quantise"):

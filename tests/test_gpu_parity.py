@@ -302,7 +302,7 @@ def test_predict_accumulate_continues_the_sum_on_every_strategy(env):
 
 
 def test_region_form_two_and_three_chains(env, monkeypatch):
-    """QRING's region layout (num_cols <= 256): tiles of three 64-row regions (13 walkers x 3 chains) or two (15 x 2), picked
+    """QRING's region layout (num_cols <= 256): tiles of three 64-row regions (14 walkers x 3 chains) or two (15 x 2), picked
     per batch; both forced here, plus the 128-slot column layout it replaces, on ragged row counts, with missing values
     confined to a few rows so that a 192-row tile straddles a quantise chunk that saw none and one that did."""
     ta, oracle, torch = env

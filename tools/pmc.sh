@@ -4,7 +4,9 @@
 # with: gpurun_out/pmc_<tag>.json.  Copy the ones to be judged into profiles/.
 # usage: tools/pmc.sh <tag> [bench args...]      env PASSES="a b c d e" selects passes
 export TMPDIR=/tmp
+set -e
 R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd "$R"
 tag=$1; shift
 BENCH_ARGS="$*"
 PASSES=${PASSES:-"a b c d e"}
@@ -19,7 +21,8 @@ pass e WRITE_SIZE && \
 python3 - <<PY
 import csv, glob, collections, json, sys
 sys.path.insert(0, "$R")
-import bench
+import bench, torch
+prop = torch.cuda.get_device_properties(0)
 kern = collections.defaultdict(lambda: collections.defaultdict(list))
 for n in "abcde":
     for f in glob.glob("$R/gpurun_out/pmc_${tag}_%s/*/*_counter_collection.csv" % n):
@@ -28,7 +31,7 @@ for n in "abcde":
                 kern[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {"note": "rocprofv3 --pmc passes a-e (tools/pmc.sh; each pass its own run, no trace domains) over bench.py --steps 2 --warmup 1 "
                "--no-cpu --no-host --no-k4 $BENCH_ARGS; averages per launch, counters summed over the chip; FETCH_SIZE / WRITE_SIZE in KB",
-       "src_hash": bench.kernel_source_hash(), "num_cus": 256, "clock_ghz": 2.4,
+       "src_hash": bench.kernel_source_hash(), "num_cus": prop.multi_processor_count, "clock_ghz": getattr(prop, "clock_rate", 2400000) / 1e6,
        "kernels": {k: {c: sum(v) / len(v) for c, v in sorted(cs.items())} for k, cs in sorted(kern.items())}}
 json.dump(out, open("$R/gpurun_out/pmc_${tag}.json", "w"), indent=1)
 for k, cs in out["kernels"].items():

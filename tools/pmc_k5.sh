@@ -1,6 +1,9 @@
+#!/bin/bash
+# superseded by tools/pmc_script.sh k5 tools/pmc_target.py K5 4; kept for the round-2 profile it produced
+set -e
 export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-cd $R
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd "$R"
 rm -rf gpurun_out/k5pmc_a gpurun_out/k5pmc_b gpurun_out/k5pmc_c
 timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU --output-format csv -d gpurun_out/k5pmc_a -- python3 tools/k5_time.py > gpurun_out/k5pmc_a.log 2>&1 &&
 timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY --output-format csv -d gpurun_out/k5pmc_b -- python3 tools/k5_time.py > gpurun_out/k5pmc_b.log 2>&1 &&
