@@ -31,8 +31,10 @@ for n in "abcde":
                 kern[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {"note": "rocprofv3 --pmc passes a-e (tools/pmc.sh; each pass its own run, no trace domains) over bench.py --steps 2 --warmup 1 "
                "--no-cpu --no-host --no-k4 $BENCH_ARGS; averages per launch, counters summed over the chip; FETCH_SIZE / WRITE_SIZE in KB",
+       "script": "bench.py --steps 2 --warmup 1 (predicts per run:) 3",
        "src_hash": bench.kernel_source_hash(), "num_cus": prop.multi_processor_count, "clock_ghz": getattr(prop, "clock_rate", 2400000) / 1e6,
-       "kernels": {k: {c: sum(v) / len(v) for c, v in sorted(cs.items())} for k, cs in sorted(kern.items())}}
+       "kernels": {k: dict({c: sum(v) / len(v) for c, v in sorted(cs.items())}, launches=len(next(iter(cs.values()))))
+                   for k, cs in sorted(kern.items())}}
 json.dump(out, open("$R/gpurun_out/pmc_${tag}.json", "w"), indent=1)
 for k, cs in out["kernels"].items():
     print(k[-70:], {c: "%.4g" % v for c, v in cs.items()})
