@@ -618,15 +618,18 @@ def test_quantiser_on_skewed_thresholds(env, monkeypatch, form):
     run_case(env, nodes, T, D, C, data, strategies=[ta.STRATEGY_QRING, ta.STRATEGY_TILERING])
 
 
-def test_predict_is_capturable_in_a_hip_graph(env):
+@pytest.mark.parametrize("T,D,C,R", [(120, 8, 18, 10_000),    # K1-like: memset + quantise + walk (tree slices + ordered sum) + transform
+                                     (200, 7, 2048, 5_000)])  # wide rows, the row-streaming form: its leaf-value workspace is reserved
+def test_predict_is_capturable_in_a_hip_graph(env, T, D, C, R):
     """A predict on a reserved handle is a fixed sequence of stream operations (a memset, the quantise and walk
     kernels, the output transform): no allocation, no synchronisation.  It can therefore be captured into a
     hipGraph once and replayed -- the way a launch-bound caller (K1: 10 k rows, three launches per batch) removes
     the per-launch host cost.  Replays must give the oracle's bits, also after the input buffer changes."""
     ta, oracle, torch = env
-    T, D, C, R = 120, 8, 18, 10_000
     nodes = ta.synth_forest(T, D, C, seed=91, leaf_prob=0.05)
     f = ta.Forest(nodes, T, D, C, missing=MISSING, output=ta.OUT_AVG | ta.OUT_SIGMOID, global_bias=0.1)
+    if C > 512:
+        assert f.info().stream_slots > 0 and f.get_strategy(R) == ta.STRATEGY_TILERING
     f.reserve(R)
     x = torch.empty((R, C), dtype=torch.float32, device="cuda")
     out = torch.zeros(R, dtype=torch.float32, device="cuda")
