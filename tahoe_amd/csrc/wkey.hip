@@ -2,10 +2,11 @@
 // of Struct.h:953-1704 for shapes where a row does not fit shared memory; the layout is the reference's own idea for
 // "lane = tree" -- node-major `reorg` arrays (Struct.h:1911-1923, walker :1035-1071) -- moved into LDS.
 //
-// What the tile form (widef.hip) costs on K2 (500 trees of depth 8, 3072 features; profiles/r03/pmc_k2.json): one workgroup per
+// What the tile form (widef.hip) costs on K2 (500 trees of depth 8, 3072 features; profiles/r03/pmc_k2_tileform.json): one workgroup per
 // CU with LDS full, so nothing overlaps the staging of a tile; every 8-row tile re-stages the tops of all trees from L2 (2.6 x
 // the bytes of the rows); and every walk gathers three 16-byte pieces of a bottom block.  The texture path is what binds
-// (TD 73 % busy, HBM at 20 % of its peak): a divergent gather costs it about a cycle per LANE whatever its width.  A first
+// (TD 73 % busy, HBM at 20 % of its peak): a divergent gather costs it 85-130 cycles whatever its width or its number of active
+// lanes, a coalesced 1-KiB load 16 (profiles/r03/experiments.json).  A first
 // row-streaming form on float32 rows (profiles/r03/wstream_ablation.txt) could keep only five levels of all trees resident
 // beside four 12-KiB rows and needed five gathers per walk: 0.91 ms against the tile form's 0.78.
 //
@@ -24,20 +25,21 @@
 //   * ONE persistent workgroup per CU keeps the first lw levels of ALL trees in LDS for its whole life, node-major u32 words
 //     key << 16 | fid << 1 | def_left, tree stride a power of two: lane = tree, so a node read is conflict-free whatever node
 //     each lane stands on, the two children of heap position p are one ds_read2st64_b32 at (p << log2(8 stride)) + lane
-//     constant, and a level costs 7 VALU + 2 LDS instructions per 64 walks (the first, portable version of this loop took 45:
+//     constant, and a level costs 12 vector instructions per 64 walks (the first, portable version of this loop took 45:
 //     the CU issues one vector instruction per cycle, and that -- not memory -- was what bound it);
-//   * kWkLoaders loader waves pull the rows of the workgroup's share of the batch through registers (16-byte loads, two
-//     4-KiB chunks in flight per wave), turn them into keys and store them into a ring of S row slots;
-//   * a walker wave takes item (row k, chunk c) = 64 trees of one row: lw levels from LDS, the last two levels and the leaf
+//   * kWkLoaders loader waves pull the rows of the workgroup's share of the batch through registers (16-byte loads, a whole
+//     row in flight per wave), turn them into keys at once and keep the keys in registers until their slot of the ring of S
+//     row slots is free;
+//   * a walker wave takes item (row k, two chunks of 64 trees): lw levels from LDS, the last two levels and the leaf
 //     from ONE 32-byte block per walk (two gathers; the tile form's 48-byte float32 block takes three), levels in between
 //     (deep trees only) from the heap records with the float32 rule; leaf value into the workspace; the last walker of a row
 //     frees its slot;
 //   * the leaf values go to a workspace in global memory, leaf[row][tree] (coalesced 256-byte stores), and a summer wave of the
 //     same workgroup adds them 64 rows at a time, one lane per row, in tree order: float32 sums bit-identical to predict_on_cpu
-//     (BaseTahoeTest.h:462-466).  (Consumer waves inside the kernel -- the scheme of the tile kernels -- were tried first: with four rows in LDS
-//     only four 500-term dependent chains can be under way, one lane each, ~19 cycles per add beside 12 busy waves: they cost
-//     0.17 of 0.65 ms whatever their number, profiles/r03/wkey_experiments.txt.  The workspace costs 2 x 4 bytes per (row, tree)
-//     of traffic, most of it absorbed by the 256-MiB Infinity Cache.)
+//     (BaseTahoeTest.h:462-466).  (Consumer waves fed through LDS -- the scheme of the tile kernels -- were built first: with
+//     four rows in LDS only four 500-term dependent chains can be under way, one lane each, ~19 cycles per add beside 12 busy
+//     waves: 0.17 of 0.65 ms whatever their number, profiles/r03/experiments.json.  The workspace costs 2 x 4 bytes per (row,
+//     tree) of traffic, most of it absorbed by the 256-MiB Infinity Cache.)
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -55,17 +57,17 @@ namespace tahoe {
 #define TAHOE_WK_WALKERS 11
 #endif
 constexpr int kWkLoaders = TAHOE_WK_LOADERS;  // loader waves (= the fewest row slots)
-constexpr int kWkWalkers = TAHOE_WK_WALKERS;  // walker waves; 4 loaders + 1 summer + 11 walkers = 16 waves (K2: 0.592 ms; 5 + 10: 0.604, 3 + 12: 0.621)
+constexpr int kWkWalkers = TAHOE_WK_WALKERS;  // walker waves; 4 loaders + 1 summer + 11 walkers = 16 waves (K2: 0.59 ms; 5 + 10: 0.60, 3 + 12: 0.62)
 constexpr int kWkSumRows = 64;                // rows the summer wave adds at once, one lane each
 #ifndef TAHOE_WK_CHAINS
 #define TAHOE_WK_CHAINS 2
 #endif
-constexpr int kWkChains = TAHOE_WK_CHAINS;  // 64-tree chunks of one row a walker wave walks at once (chains per lane)
+constexpr int kWkChains = TAHOE_WK_CHAINS;  // 64-tree chunks of one row a walker wave walks at once (chains per lane; 3: 0.63 ms, 4: 0.61)
 constexpr int kWkSpinLimit = 1 << 22;
 constexpr uint32_t kWkMissing = 0xFFFFu;
 
 // Timing-only ablation builds (make ABLATE=n; results are wrong on purpose; never shipped): 1 = no bottom-block gathers,
-// 2 = walkers only pass the rows on, 3 = the loaders load nothing, 4 = the consumers add nothing; 5 = 2 + 4 (loaders alone),
+// 2 = walkers only pass the rows on, 3 = the loaders load nothing, 4 = the summer adds nothing; 5 = 2 + 4 (loaders alone),
 // 6 = 3 + 4 (walkers alone).
 #ifndef TAHOE_WS_ABLATE
 #define TAHOE_WS_ABLATE 0
@@ -75,8 +77,6 @@ constexpr uint32_t kWkMissing = 0xFFFFu;
 #define WK_NO_LOAD (TAHOE_WS_ABLATE == 3 || TAHOE_WS_ABLATE == 6)
 #define WK_NO_ADD (TAHOE_WS_ABLATE == 4 || TAHOE_WS_ABLATE == 5 || TAHOE_WS_ABLATE == 6)
 
-// The key of a float given by its bits; the same integer arithmetic on the host (thresholds, at create) and on the device
-// (feature values, in the loader) -- no float operation, so denormal modes cannot make the two disagree.
 // The key of a non-missing value: NaN -> 0 (v_max_f32 returns its other operand), below lo -> 0, above hi -> 65534.
 __device__ __forceinline__ uint32_t wk_key(float x, float lo, float scale)
 {
@@ -116,8 +116,8 @@ template <int TSL, bool WRITE_LEAF>
 __global__ void __launch_bounds__((kWkLoaders + 1 + kWkWalkers) * 64)
     wkey_kernel(const float *__restrict__ data, const unsigned char *__restrict__ kimg, const uint4 *__restrict__ kblocks,
                 const InnerNode *__restrict__ inner, const uint32_t *__restrict__ leaf_orig, float *__restrict__ leafbuf,
-                float *sums, const float *sums_in, uint32_t *__restrict__ leaf_out, size_t rows, int cols, int num_trees, int depth, int lw, int img_bytes, int S, float missing,
-                float key_lo, float key_scale, int *__restrict__ error_flag)
+                float *sums, const float *sums_in, uint32_t *__restrict__ leaf_out, size_t rows, int cols, int num_trees, int depth, int lw,
+                int img_bytes, int S, float missing, float key_lo, float key_scale, int *__restrict__ error_flag)
 {
     constexpr int NL = kWkLoaders, NW = kWkLoaders + 1 + kWkWalkers;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
