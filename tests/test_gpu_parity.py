@@ -857,3 +857,40 @@ def test_wide_rows_streaming_form_equal_keys(env, monkeypatch):
     f.set_strategy(ta.STRATEGY_DIRECT)
     assert np.array_equal(bits(f.predict_raw(x).cpu().numpy()), bits(want))
     f.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["constant_thresholds", "infinite_and_nan_thresholds", "one_tree", "huge_values"])
+def test_wide_rows_streaming_form_degenerate_key_maps(env, monkeypatch, case):
+    """The key map of the row-streaming form is built from the range of the forest's finite thresholds: all thresholds equal
+    (scale 0: every compare ties and is decided on the float32 values), +-inf / NaN thresholds (keys at the ends / 0xFFFF),
+    a single tree, features far outside the thresholds' range (clamped keys)."""
+    ta, oracle, torch = env
+    monkeypatch.setenv("TAHOE_WSTREAM", "1")
+    T, D, C, R = (1 if case == "one_tree" else 70), 5, 768, 900
+    nodes = ta.synth_forest(T, D, C, seed=980, leaf_prob=0.1).copy()
+    data = ta.synth_data(R, C, seed=981, missing_prob=0.02, missing=MISSING, nan_prob=0.01)
+    inner = nodes["bits"] >= 0  # is_leaf is the sign bit
+    if case == "constant_thresholds":
+        nodes["val"][inner] = np.float32(0.25)
+        data[::3, ::5] = np.float32(0.25)
+    elif case == "infinite_and_nan_thresholds":
+        idx = np.flatnonzero(inner)
+        nodes["val"][idx[::7]] = np.float32(np.inf)
+        nodes["val"][idx[3::11]] = np.float32(-np.inf)
+        nodes["val"][idx[5::13]] = np.float32(np.nan)
+        data[::4, ::9] = np.float32(np.inf)
+        data[1::4, ::9] = np.float32(-np.inf)
+    elif case == "huge_values":
+        data[::2] *= np.float32(1e30)
+        data[1::5, ::3] = np.float32(3.0e38)
+    f = ta.Forest(nodes, T, D, C, missing=MISSING)
+    assert f.info().stream_slots >= 4
+    f.set_strategy(ta.STRATEGY_TILERING)
+    want, want_leaf = oracle.predict(nodes, T, D, data, MISSING, want_leaf=True, threads=8)
+    x = torch.from_numpy(data).cuda()
+    leaf, sums = f.predict_leaf_idx(x)
+    f.check()
+    assert np.array_equal(bits(leaf.cpu().numpy()), want_leaf)
+    assert np.array_equal(bits(sums.cpu().numpy()), bits(want))
+    f.close()
