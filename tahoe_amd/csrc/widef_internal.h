@@ -16,6 +16,7 @@ struct tahoe_wstate {
     int s_lw = 0, s_ts = 0, s_slots = 0, s_img_bytes = 0;
     float *leafbuf = nullptr;       // workspace [leaf_rows][trees rounded up to 32]: leaf values of a batch, added in tree order by the kernel's summer wave
     size_t leaf_rows = 0;
+    size_t slab_bytes = 0;          // cap of the workspace: larger batches are walked in slabs of rows
     float key_lo = 0.f, key_scale = 0.f;  // key(x) = trunc(clamp((x - key_lo) * key_scale, 0, 65534))
     bool s_on = false;              // the launch takes it
 };

@@ -571,6 +571,8 @@ tahoe_status wkey_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner, 
     w->s_ts = s_ts;
     w->s_slots = slots;
     w->s_img_bytes = (int)img;
+    w->slab_bytes = (size_t)1 << 30;
+    if (const char *sm = getenv("TAHOE_WSTREAM_SLAB_MB")) w->slab_bytes = (size_t)std::max(atoi(sm), 1) << 20;
     w->key_lo = lo;
     w->key_scale = scale;
     w->s_on = true;
@@ -582,11 +584,21 @@ tahoe_status wkey_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner, 
     return TAHOE_OK;
 }
 
-// The leaf-value workspace, [rows][trees rounded up to 32] floats (whole 128-byte lines per row), grow-only like the quantised forms' (tahoe_forest_reserve).
+// The leaf-value workspace, [rows][trees rounded up to 32] floats (whole 128-byte lines per row), grow-only like the quantised
+// forms' (tahoe_forest_reserve).  At most 1 GiB (TAHOE_WSTREAM_SLAB_MB, read at create): a larger batch is walked in slabs of
+// rows, one launch after the other on the stream, each re-using the workspace.
+static size_t wk_slab_rows(const tahoe_forest *f)
+{
+    const size_t tv = ((size_t)f->p.num_trees + 31) & ~(size_t)31;
+    return std::max<size_t>(f->wf->slab_bytes / (tv * sizeof(float)), (size_t)std::max(f->num_cus, 1) * 64);
+}
+
 tahoe_status wkey_reserve(tahoe_forest *f, size_t rows)
 {
     tahoe_wstate *w = f->wf;
-    if (!w || !w->s_on || rows <= w->leaf_rows) return TAHOE_OK;
+    if (!w || !w->s_on) return TAHOE_OK;
+    rows = std::min(rows, wk_slab_rows(f));
+    if (rows <= w->leaf_rows) return TAHOE_OK;
     const size_t tv = ((size_t)f->p.num_trees + 31) & ~(size_t)31;
     if (w->leafbuf) {
         TAHOE_HIP_TRY(hipDeviceSynchronize());  // a previous launch may still use the old buffer
@@ -611,24 +623,32 @@ tahoe_status wkey_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, const
     }
     const size_t nch = ((size_t)f->p.num_trees + 63) / 64;
     const size_t max_per = ((size_t)1 << 30) / nch;  // rows x chunks of one workgroup stay within int
-    size_t grid = std::min<size_t>(rows, (size_t)std::max(f->num_cus, 1));  // one persistent workgroup per CU
-    grid = std::max(grid, (rows + max_per - 1) / max_per);
     const int lds = (int)wkey_lds_bytes(f);
     const dim3 block((kWkLoaders + 1 + kWkWalkers) * 64);
     float *leafbuf = sums ? w->leafbuf : nullptr;
-    auto go = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), block, lds, stream, data, w->kimg, w->kblocks, f->inner, f->leaf_orig, leafbuf, sums, sums_in,
-                           leaf_out, rows, f->p.num_cols, f->p.num_trees, f->depth, w->s_lw, w->s_img_bytes, w->s_slots, f->p.missing, w->key_lo,
-                           w->key_scale, f->error_flag);
-    };
-    switch (w->s_ts) {
-    case 64: leaf_out ? go(wkey_kernel<6, true>) : go(wkey_kernel<6, false>); break;
-    case 128: leaf_out ? go(wkey_kernel<7, true>) : go(wkey_kernel<7, false>); break;
-    case 256: leaf_out ? go(wkey_kernel<8, true>) : go(wkey_kernel<8, false>); break;
-    case 512: leaf_out ? go(wkey_kernel<9, true>) : go(wkey_kernel<9, false>); break;
-    default: leaf_out ? go(wkey_kernel<10, true>) : go(wkey_kernel<10, false>); break;
+    const size_t slab = sums ? wk_slab_rows(f) : rows;
+    for (size_t lo = 0; lo < rows; lo += slab) {
+        const size_t n = std::min(slab, rows - lo);
+        size_t grid = std::min<size_t>(n, (size_t)std::max(f->num_cus, 1));  // one persistent workgroup per CU
+        grid = std::max(grid, (n + max_per - 1) / max_per);
+        const float *d = data + lo * (size_t)f->p.num_cols;
+        float *so = sums ? sums + lo : nullptr;
+        const float *si = sums_in ? sums_in + lo : nullptr;
+        uint32_t *lf = leaf_out ? leaf_out + lo * (size_t)f->p.num_trees : nullptr;
+        auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3((unsigned)grid), block, lds, stream, d, w->kimg, w->kblocks, f->inner, f->leaf_orig, leafbuf, so, si, lf, n,
+                               f->p.num_cols, f->p.num_trees, f->depth, w->s_lw, w->s_img_bytes, w->s_slots, f->p.missing, w->key_lo,
+                               w->key_scale, f->error_flag);
+        };
+        switch (w->s_ts) {
+        case 64: leaf_out ? go(wkey_kernel<6, true>) : go(wkey_kernel<6, false>); break;
+        case 128: leaf_out ? go(wkey_kernel<7, true>) : go(wkey_kernel<7, false>); break;
+        case 256: leaf_out ? go(wkey_kernel<8, true>) : go(wkey_kernel<8, false>); break;
+        case 512: leaf_out ? go(wkey_kernel<9, true>) : go(wkey_kernel<9, false>); break;
+        default: leaf_out ? go(wkey_kernel<10, true>) : go(wkey_kernel<10, false>); break;
+        }
+        TAHOE_HIP_TRY(hipGetLastError());
     }
-    TAHOE_HIP_TRY(hipGetLastError());
     return TAHOE_OK;
 }
 

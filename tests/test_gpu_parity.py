@@ -894,3 +894,30 @@ def test_wide_rows_streaming_form_degenerate_key_maps(env, monkeypatch, case):
     assert np.array_equal(bits(leaf.cpu().numpy()), want_leaf)
     assert np.array_equal(bits(sums.cpu().numpy()), bits(want))
     f.close()
+
+
+@pytest.mark.gpu
+def test_wide_rows_streaming_form_walks_large_batches_in_slabs(env, monkeypatch):
+    """The leaf-value workspace of the row-streaming form is capped (1 GiB; here 1 MiB -> the floor of 64 rows per CU): a larger
+    batch is walked slab by slab on the stream, also with continued sums and leaf indices."""
+    ta, oracle, torch = env
+    monkeypatch.setenv("TAHOE_WSTREAM", "1")
+    monkeypatch.setenv("TAHOE_WSTREAM_SLAB_MB", "1")
+    T, D, C = 40, 6, 640
+    nodes = ta.synth_forest(T, D, C, seed=990, leaf_prob=0.1)
+    f = ta.Forest(nodes, T, D, C, missing=MISSING)
+    R = f.info().num_cus * 64 * 2 + 777  # two full slabs and a ragged third
+    data = ta.synth_data(R, C, seed=991, missing_prob=0.01, missing=MISSING)
+    f.set_strategy(ta.STRATEGY_TILERING)
+    assert f.info().stream_slots >= 4
+    x = torch.from_numpy(data).cuda()
+    want, want_leaf = oracle.predict(nodes, T, D, data, MISSING, want_leaf=True, threads=8)
+    leaf, sums = f.predict_leaf_idx(x)
+    f.check()
+    assert np.array_equal(bits(leaf.cpu().numpy()), want_leaf)
+    assert np.array_equal(bits(sums.cpu().numpy()), bits(want))
+    start = np.linspace(-1.0, 1.0, R).astype(np.float32)
+    acc = f.predict_accumulate(x, torch.from_numpy(start.copy()).cuda())
+    f.check()
+    assert np.array_equal(bits(acc.cpu().numpy()), bits(oracle.predict_continue(nodes, T, D, data, MISSING, start)))
+    f.close()
