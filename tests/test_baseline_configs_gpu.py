@@ -87,6 +87,9 @@ def test_k2_svhn_like_wide_rows(env):
     forest.set_strategy(ta.STRATEGY_QRING)
     assert np.array_equal(bits(forest.predict_raw(x).cpu().numpy()), bits(got))  # every row, the other wide form
     forest.set_strategy(ta.STRATEGY_AUTO)
+    assert forest.info().stream_slots >= 4  # ... as the row-streaming kernel on 16-bit keys (wkey.hip)
+    want_all, _ = oracle.predict(nodes, T, D, data, MISSING, threads=16)  # every row against the oracle (4e8 node visits)
+    assert np.array_equal(bits(got), bits(want_all))
     idx = strided(R, 50)
     want, want_leaf = oracle.predict(nodes, T, D, data[idx], MISSING, want_leaf=True, threads=8)
     assert np.array_equal(bits(got[idx]), bits(want))
