@@ -223,8 +223,8 @@ def test_golden_fixtures(env):
 
 
 def test_k3_full_size_properties(env):
-    """BASELINE config 3 at full size (1000 trees, depth 12, 256 features, 1M rows): oracle on a strided
-    sample of rows, and size-independent properties on all rows."""
+    """BASELINE config 3 at full size (1000 trees, depth 12, 256 features, 1M rows): every sum against the oracle, leaf
+    indices on a strided sample of rows, and size-independent properties on all rows."""
     ta, oracle, torch = env
     T, D, C, R = 1000, 12, 256, 1_000_000
     nodes = ta.synth_forest(T, D, C, seed=42)
@@ -240,6 +240,9 @@ def test_k3_full_size_properties(env):
     assert np.array_equal(bits(got[idx]), bits(want))
     leaf, _ = forest.predict_leaf_idx(x[torch.from_numpy(idx).cuda()].contiguous(), want_sums=False)
     assert np.array_equal(bits(leaf.cpu().numpy()), want_leaf)
+    # (1b) EVERY row of the batch against the oracle (1e6 rows x 1000 trees x 12 levels = 1.2e10 node visits on the host)
+    want_all, _ = oracle.predict(nodes, T, D, data, MISSING, threads=32)
+    assert np.array_equal(bits(got), bits(want_all))
     # (2) two independent kernels agree on every row
     forest.set_strategy(ta.STRATEGY_DIRECT)
     d_sums = forest.predict_raw(x[: 200_000].contiguous()).cpu().numpy()
