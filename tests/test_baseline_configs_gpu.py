@@ -117,6 +117,10 @@ def test_k4_8000_trees_one_gpu_and_tree_shards(env):
     idx = strided(R, 997)[:1100]
     want, want_leaf = oracle.predict(nodes, T, D, data[idx], MISSING, want_leaf=True, threads=8)
     assert np.array_equal(bits(got[idx]), bits(want))
+    # ... and every row of the first and the last 30 k (5.8e9 node visits on the host)
+    for lo, hi in ((0, 30_000), (R - 30_000, R)):
+        w, _ = oracle.predict(nodes, T, D, data[lo:hi], MISSING, threads=32)
+        assert np.array_equal(bits(got[lo:hi]), bits(w)), (lo, hi)
     xs = x[torch.from_numpy(idx).cuda()].contiguous()
     leaf, _ = forest.predict_leaf_idx(xs[:256].contiguous(), want_sums=False)
     assert np.array_equal(bits(leaf.cpu().numpy()), want_leaf[:256])
@@ -176,6 +180,8 @@ def test_k5_irregular_sparse_forest(env):
     forest = ta.capi.SparseForest(sn, tr, C, missing=MISSING)
     got = forest.predict_raw(x).cpu().numpy()
     forest.check()
+    want_all, _ = oracle.sparse_predict(sn, tr, data, MISSING, threads=32)  # every row against the oracle
+    assert np.array_equal(bits(got), bits(want_all))
     idx = strided(R, 400)
     want, want_leaf = oracle.sparse_predict(sn, tr, data[idx], MISSING, want_leaf=True, threads=8)
     assert np.array_equal(bits(got[idx]), bits(want))
