@@ -330,72 +330,94 @@ __global__ void __launch_bounds__((kWkLoaders + 1 + kWkWalkers) * 64)
             return right;
         };
         auto xkey = [&](uint32_t node) -> uint32_t { return *reinterpret_cast<wk_lds_u16>((node & 0xFFFEu) + xbase); };
-        uint32_t p[KC], node[KC], cbase[KC];  // 1-based heap position, node word, lane constant of the child-pair address
-#pragma unroll
-        for (int j = 0; j < KC; ++j) {
-            p[j] = 1;
-            cbase[j] = 4u * (uint32_t)tt[j] - (4u << TSL);  // children of p: position 2p at ((2p - 1) << TSL) + tt dwords
-            node[j] = lw > 0 ? *reinterpret_cast<wk_lds_u32>(4u * (uint32_t)tt[j]) : 0u;
-        }
-#if WK_NO_WALK
-        if (false)
-#endif
-        if (lw > 0) {
-            for (int l = 0; l < lw - 1; ++l) {
-                // one LDS round trip per level: the feature key of the node and BOTH children (one tree stride apart)
-                uint32_t kx[KC], nl[KC], nr[KC];
-#pragma unroll
-                for (int j = 0; j < KC; ++j) {
-                    kx[j] = xkey(node[j]);
-                    const wk_lds_u32 cp = reinterpret_cast<wk_lds_u32>((p[j] << (TSL + 3)) + cbase[j]);
-                    nl[j] = cp[0];
-                    nr[j] = cp[1 << TSL];
-                }
-#pragma unroll
-                for (int j = 0; j < KC; ++j) {
-                    const uint64_t r = right_mask(node[j], kx[j], tree[j], p[j] - 1u);
-                    p[j] = wk_descend(p[j], r);
-                    node[j] = __builtin_amdgcn_inverse_ballot_w64(r) ? nr[j] : nl[j];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < KC; ++j) p[j] = wk_descend(p[j], right_mask(node[j], xkey(node[j]), tree[j], p[j] - 1u));
-        }
+        // Chains are walked in groups of GS = 2: the LDS levels of a group interleave its chains (one LDS round trip per level
+        // and two walks under way); with four chains the bottom-block gathers of the first group fly under the LDS levels of
+        // the second.
+        constexpr int GS = KC < 2 ? KC : 2;
+        static_assert(KC == 1 || KC == 2 || KC == 4, "chains per walker: 1, 2 or 4");
+        uint32_t p[KC];  // 1-based heap position per chain
         float leaf[KC];
-        uint32_t bsel[KC], c0[KC], c1[KC];
-#if WK_NO_GATHER || WK_NO_WALK
-#pragma unroll
-        for (int j = 0; j < KC; ++j) {
-            bsel[j] = c0[j] = c1[j] = 0;
-            leaf[j] = __uint_as_float(p[j]);
-        }
-#else
+        uint32_t bsel[KC], c0[KC], c1[KC], idx[KC];
         uint4 qa[KC], qb[KC];
-        uint32_t idx[KC];
+        auto top = [&](auto j0c) {  // the resident levels of chains j0 .. j0 + GS - 1
+            constexpr int J0 = decltype(j0c)::value;
+            uint32_t node[GS], cbase[GS];  // node word, lane constant of the child-pair address
 #pragma unroll
-        for (int j = 0; j < KC; ++j) {
-            idx[j] = p[j] - 1u;  // 0-based heap index on level lw
-            for (int l = lw; l < depth - 2; ++l) {  // deep trees only: the float32 rule on the heap records in global memory
-                const InnerNode nd = tree[j][idx[j]];
-                idx[j] = 2u * idx[j] + 1u + go_right(xrow[nd.meta & kMetaFidMask], nd.thr, (nd.meta >> 31) != 0u, missing);
+            for (int g = 0; g < GS; ++g) {
+                p[J0 + g] = 1;
+                cbase[g] = 4u * (uint32_t)tt[J0 + g] - (4u << TSL);  // children of p: position 2p at ((2p - 1) << TSL) + tt dwords
+                node[g] = lw > 0 ? *reinterpret_cast<wk_lds_u32>(4u * (uint32_t)tt[J0 + g]) : 0u;
             }
-            // the last two levels and the leaf: {n0, n1, n2, leaf0} {leaf1, leaf2, leaf3, -}, one 32-byte block per walk
-            bsel[j] = idx[j] - first_block_node;
-            const uint4 *bp = kblocks + ((size_t)tt[j] * n_blocks + bsel[j]) * 2;
-            qa[j] = bp[0];
-            qb[j] = bp[1];
-        }
-#pragma unroll
-        for (int j = 0; j < KC; ++j) {
-            const bool r0b = __builtin_amdgcn_inverse_ballot_w64(right_mask(qa[j].x, xkey(qa[j].x), tree[j], idx[j]));
-            c0[j] = r0b ? 1u : 0u;
-            const uint32_t n1 = r0b ? qa[j].z : qa[j].y;
-            const bool r1b = __builtin_amdgcn_inverse_ballot_w64(right_mask(n1, xkey(n1), tree[j], 2u * idx[j] + 1u + c0[j]));
-            c1[j] = r1b ? 1u : 0u;
-            const uint32_t lo = r0b ? qb[j].y : qa[j].w, hi = r0b ? qb[j].z : qb[j].x;
-            leaf[j] = __uint_as_float(r1b ? hi : lo);
-        }
+#if WK_NO_WALK
+            if (false)
 #endif
+            if (lw > 0) {
+                for (int l = 0; l < lw - 1; ++l) {
+                    // one LDS round trip per level: the feature key of the node and BOTH children (one tree stride apart)
+                    uint32_t kx[GS], nl[GS], nr[GS];
+#pragma unroll
+                    for (int g = 0; g < GS; ++g) {
+                        kx[g] = xkey(node[g]);
+                        const wk_lds_u32 cp = reinterpret_cast<wk_lds_u32>((p[J0 + g] << (TSL + 3)) + cbase[g]);
+                        nl[g] = cp[0];
+                        nr[g] = cp[1 << TSL];
+                    }
+#pragma unroll
+                    for (int g = 0; g < GS; ++g) {
+                        const uint64_t r = right_mask(node[g], kx[g], tree[J0 + g], p[J0 + g] - 1u);
+                        p[J0 + g] = wk_descend(p[J0 + g], r);
+                        node[g] = __builtin_amdgcn_inverse_ballot_w64(r) ? nr[g] : nl[g];
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < GS; ++g)
+                    p[J0 + g] = wk_descend(p[J0 + g], right_mask(node[g], xkey(node[g]), tree[J0 + g], p[J0 + g] - 1u));
+            }
+        };
+        auto gather = [&](auto j0c) {  // levels between tops and blocks (deep trees only), then the bottom block's two pieces
+            constexpr int J0 = decltype(j0c)::value;
+#pragma unroll
+            for (int j = J0; j < J0 + GS; ++j) {
+#if WK_NO_GATHER || WK_NO_WALK
+                bsel[j] = c0[j] = c1[j] = idx[j] = 0;
+                leaf[j] = __uint_as_float(p[j]);
+#else
+                idx[j] = p[j] - 1u;  // 0-based heap index on level lw
+                for (int l = lw; l < depth - 2; ++l) {  // the float32 rule on the heap records in global memory
+                    const InnerNode nd = tree[j][idx[j]];
+                    idx[j] = 2u * idx[j] + 1u + go_right(xrow[nd.meta & kMetaFidMask], nd.thr, (nd.meta >> 31) != 0u, missing);
+                }
+                // the last two levels and the leaf: {n0, n1, n2, leaf0} {leaf1, leaf2, leaf3, -}, one 32-byte block per walk
+                bsel[j] = idx[j] - first_block_node;
+                const uint4 *bp = kblocks + ((size_t)tt[j] * n_blocks + bsel[j]) * 2;
+                qa[j] = bp[0];
+                qb[j] = bp[1];
+#endif
+            }
+        };
+        auto bottom = [&](auto j0c) {
+            constexpr int J0 = decltype(j0c)::value;
+#if !(WK_NO_GATHER || WK_NO_WALK)
+#pragma unroll
+            for (int j = J0; j < J0 + GS; ++j) {
+                const bool r0b = __builtin_amdgcn_inverse_ballot_w64(right_mask(qa[j].x, xkey(qa[j].x), tree[j], idx[j]));
+                c0[j] = r0b ? 1u : 0u;
+                const uint32_t n1 = r0b ? qa[j].z : qa[j].y;
+                const bool r1b = __builtin_amdgcn_inverse_ballot_w64(right_mask(n1, xkey(n1), tree[j], 2u * idx[j] + 1u + c0[j]));
+                c1[j] = r1b ? 1u : 0u;
+                const uint32_t lo = r0b ? qb[j].y : qa[j].w, hi = r0b ? qb[j].z : qb[j].x;
+                leaf[j] = __uint_as_float(r1b ? hi : lo);
+            }
+#endif
+        };
+        top(std::integral_constant<int, 0>{});
+        gather(std::integral_constant<int, 0>{});
+        if constexpr (KC > GS) {
+            top(std::integral_constant<int, GS>{});
+            gather(std::integral_constant<int, GS>{});
+        }
+        bottom(std::integral_constant<int, 0>{});
+        if constexpr (KC > GS) bottom(std::integral_constant<int, GS>{});
 #pragma unroll
         for (int j = 0; j < KC; ++j) {
             if (leafbuf && t[j] < num_trees) leafbuf[(r0 + k) * (size_t)tv + t[j]] = leaf[j];
