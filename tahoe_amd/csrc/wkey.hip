@@ -149,9 +149,9 @@ __global__ void __launch_bounds__((kWkLoaders + 1 + kWkWalkers) * 64)
     __syncthreads();
 
     if (wave < NL) {
-        // ================= loaders: wave j takes rows j, j + NL, ...; a row = up to four chunks of four 1-KiB pieces =================
-        // (Rows of up to three chunks, num_cols <= 3072.)  Chunk c of a row always uses register set c: the raw floats are turned into keys (kept in registers: a quarter of the
-        // raw bytes) as soon as they land, and the next row's chunk c is requested into the freed set at once -- up to a whole
+        // ================= loaders: wave j takes rows j, j + NL, ...; a row = up to three chunks of four 1-KiB pieces =================
+        // Chunk c of a row always uses register set c: the raw floats are turned into keys (kept in registers: half the raw
+        // bytes) as soon as they land, and the next row's chunk c is requested into the freed set at once -- up to a whole
         // row in flight per wave.  Only then does the wave wait for its slot: what is left on the critical path behind a freed
         // slot is a dozen ds_write_b64, not the conversion (that wait used to cost as much as the walk of the row).
         const int cpr = (row_bytes + 4095) >> 12;  // chunks per row, <= 3 (the host checks num_cols <= 3072: 128 VGPRs per lane)
