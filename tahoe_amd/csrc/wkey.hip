@@ -5,8 +5,8 @@
 // What the tile form (widef.hip) costs on K2 (500 trees of depth 8, 3072 features; profiles/r03/pmc_k2_tileform.json): one workgroup per
 // CU with LDS full, so nothing overlaps the staging of a tile; every 8-row tile re-stages the tops of all trees from L2 (2.6 x
 // the bytes of the rows); and every walk gathers three 16-byte pieces of a bottom block.  The texture path is what binds
-// (TD 73 % busy, HBM at 20 % of its peak): a divergent gather costs it 85-130 cycles whatever its width or its number of active
-// lanes, a coalesced 1-KiB load 16 (profiles/r03/experiments.json).  A first
+// (TD 73 % busy, HBM at 20 % of its peak): a wave-load costs it ~16 cycles + a price per distinct 128-byte line (0.5 from L1, 2
+// from L2, 9 from the Infinity Cache) whatever its width (tools/ubench_td.hip, profiles/r03/ubench_td.txt).  A first
 // row-streaming form on float32 rows (profiles/r03/wstream_ablation.txt) could keep only five levels of all trees resident
 // beside four 12-KiB rows and needed five gathers per walk: 0.91 ms against the tile form's 0.78.
 //
