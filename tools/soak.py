@@ -40,8 +40,10 @@ soak("K5 sparse, float32 ring", f, x[:200_000].contiguous(), 20 if QUICK else 50
 f.close()
 del x
 x = torch.from_numpy(ta.synth_data(100_000, 3072, seed=22)).cuda()
+os.environ["TAHOE_WSTREAM"] = "0"  # the tile form of wide TILERING (walker slots + LDS ring)
 f = ta.Forest(ta.synth_forest(500, 8, 3072, seed=21), 500, 8, 3072, missing=-999.0)
-soak("K2 wide, float32 ring", f, x, 40 if QUICK else 300)
+f.set_strategy(ta.STRATEGY_TILERING)
+soak("K2 wide, float32 tile form (ring)", f, x, 40 if QUICK else 300)
 f.set_strategy(ta.STRATEGY_QRING)
 soak("K2 wide, quantised ring", f, x, 40 if QUICK else 200)
 f.close()
