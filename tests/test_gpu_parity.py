@@ -752,10 +752,12 @@ def test_two_handles_on_two_streams_concurrently(env):
     (66, 12, 600, 500, 0.01),     # deep trees on 32-row tiles: eight levels in LDS, two from the heap, two in the blocks
     (129, 9, 1500, 257, 0.0),     # 16-row tiles
 ])
-def test_wide_rows_float32_form(env, T, D, C, R, missing_prob):
-    """TILERING on rows too wide for a 64-row float32 tile (widef.hip): leaf indices and sums against the oracle, continued
-    sums, and the same bits as the quantised wide form and DIRECT."""
+def test_wide_rows_float32_form(env, monkeypatch, T, D, C, R, missing_prob):
+    """TILERING on rows too wide for a 64-row float32 tile, in its tile form (widef.hip; TAHOE_WSTREAM=0 keeps the shapes the
+    row-streaming form would take on it): leaf indices and sums against the oracle, continued sums, and the same bits as the
+    quantised wide form and DIRECT."""
     ta, oracle, torch = env
+    monkeypatch.setenv("TAHOE_WSTREAM", "0")
     nodes = ta.synth_forest(T, D, C, seed=900 + T, leaf_prob=0.1 if D > 4 else 0.0)
     data = ta.synth_data(R, C, seed=901 + R, missing_prob=missing_prob, missing=MISSING, nan_prob=missing_prob / 2)
     if missing_prob:
