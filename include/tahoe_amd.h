@@ -17,9 +17,14 @@
  *                                                    -> tahoe_device_* / tahoe_compare_device
  * Every device pointer is a HIP device pointer on the handle's device; `stream` is a hipStream_t
  * passed as void* (NULL = the default stream).  All predict calls are asynchronous on `stream`
- * and allocate nothing, with one exception: the QRING strategy keeps a 2-byte-per-value quantised
- * copy of the batch in a grow-only workspace; a batch larger than any before grows it (allocation +
- * device synchronisation) unless tahoe_forest_reserve sized it beforehand.
+ * and allocate nothing, with one exception: two strategies keep a grow-only workspace on the handle --
+ * QRING a 2-byte-per-value quantised copy of the batch (plus one float per (tree, row) for the small batches it
+ * walks in tree slices), and the row-streaming form of TILERING (kernel form TAHOE_FORM_TILERING_WIDE_STREAM,
+ * which the create-time shape rule may pick with no environment variable set) one float per (row, tree rounded
+ * up to 32), capped at 1 GiB (TAHOE_WSTREAM_SLAB_MB, read at create; larger batches are walked in slabs of rows).
+ * A batch larger than any before grows the workspace inside predict: hipDeviceSynchronize + hipFree + hipMalloc,
+ * which is illegal during stream capture.  tahoe_forest_reserve(rows) sizes everything beforehand; after it no
+ * batch of up to `rows` rows allocates, and predict may be captured into a HIP graph.
  *
  * Handles share no global state and different handles may be used from different threads and streams
  * at the same time.  One handle serves one predict at a time: its workspace is reused by the next call,
@@ -40,7 +45,13 @@
 extern "C" {
 #endif
 
-#define TAHOE_AMD_ABI_VERSION 1
+#define TAHOE_AMD_ABI_VERSION 2
+
+/* The library is built with -fvisibility=hidden and a linker version script: the declarations below are its only
+ * exported symbols (tests/test_formats_capi.py checks `nm -D`). */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 /* ---- status codes (the reference prints and continues, cuda_base.h:19-25; we return codes) ---- */
 typedef enum {
@@ -220,11 +231,12 @@ tahoe_status tahoe_forest_set_strategy(tahoe_forest *f, int strategy);
 /* Waits for `stream` and reports TAHOE_ERR_HIP if a kernel flagged an internal error (a bounded
  * LDS wait of TILERING timing out); TAHOE_OK otherwise. */
 tahoe_status tahoe_forest_check(tahoe_forest *f, void *stream);
-/* Sizes the handle's device workspace for batches of up to `rows` rows (QRING keeps a 2-byte-per-value
- * quantised copy of the batch and, for the batches small enough to be walked in tree slices -- up to
- * 64 rows per CU -- one float per (tree of the largest group, row)).  Optional: predict grows the
- * workspace on demand, which is the only case in which a predict call allocates (and synchronises the
- * device); after reserve(rows) no batch of up to `rows` rows does. */
+/* Sizes the handle's device workspace for batches of up to `rows` rows: QRING's 2-byte-per-value quantised copy of
+ * the batch and, for the batches small enough to be walked in tree slices (up to 64 rows per CU), one float per
+ * (tree of the largest group, row); the row-streaming form of TILERING's leaf-value workspace, 4 bytes x rows x
+ * (trees rounded up to 32), at most 1 GiB (TAHOE_WSTREAM_SLAB_MB at create).  Optional: predict grows the
+ * workspace on demand, which is the only case in which a predict call allocates (and synchronises the device,
+ * so it cannot be captured); after reserve(rows) no batch of up to `rows` rows does. */
 tahoe_status tahoe_forest_reserve(tahoe_forest *f, size_t rows);
 
 /* Host-resident batch (the reference uploads the data file once, BaseTahoeTest.h:378-389, and
@@ -247,7 +259,6 @@ typedef struct {
     int bits_bytes;          /* b of the reference's adaptive format rule (Struct.h:1827-1852): 1, 2 or 4 */
     int lds_levels;          /* top levels staged in LDS by ROWTILE */
     size_t device_bytes;     /* device memory owned by the handle */
-    size_t path_len_sum;     /* sum over trees of ... (reserved) */
     int lds_bytes_per_block; /* dynamic LDS of the ROWTILE kernel (0 = does not fit) */
     int device_id;
     int num_cus;
@@ -265,11 +276,42 @@ typedef struct {
                               * wave); 0 = features read from the quantised tile in L2, or QRING unavailable */
     int relayout;            /* 1: created with TAHOE_CREATE_PROB_RELAYOUT */
     size_t relayout_swaps;   /* internal nodes whose subtrees changed places */
-    int stream_slots;        /* > 0: the wide-row float32 form runs as the row-streaming kernel (TAHOE_WSTREAM=1 at create):
-                              * LDS row slots of the ring the rows stream through */
+    int stream_slots;        /* > 0: TILERING runs as the row-streaming kernel on 16-bit keys (picked at create by the shape
+                              * rule -- num_cols <= 3072 and a multiple of 4, every level above the last two of all trees
+                              * resident, at most a tree per three features, key map fine enough -- or forced with
+                              * TAHOE_WSTREAM=1): LDS row slots of the ring the rows stream through */
     int stream_levels;       /* ... and the top levels of ALL trees it keeps resident in LDS */
+    float stream_key_ties;   /* create-time estimate of the share of that form's 16-bit key compares that tie and fall back
+                              * to the float32 values (one affine key map for all features: small-scale features beside
+                              * large-scale ones tie often); the shape rule takes the form only below 1e-4 */
 } tahoe_forest_info;
 tahoe_status tahoe_forest_get_info(const tahoe_forest *f, tahoe_forest_info *info);
+
+/* Which kernel a predict of `rows` rows launches (one strategy number can stand for several kernels: TILERING is
+ * tilering_kernel, widef_kernel or wkey_kernel; QRING has five tile forms).  -1 for a NULL handle. */
+enum {
+    TAHOE_FORM_NONE = 0,                  /* strategy unavailable for this shape */
+    TAHOE_FORM_DIRECT = 1,                /* direct_kernel */
+    TAHOE_FORM_ROWTILE = 2,               /* rowtile_kernel */
+    TAHOE_FORM_TILEBLOCK = 3,             /* tileblock_kernel */
+    TAHOE_FORM_TILERING_TILE = 4,         /* tilering_kernel: 64- / 128-row float32 tile, num_cols <= 512 */
+    TAHOE_FORM_TILERING_WIDE_TILE = 5,    /* widef_kernel: 32- / 16- / 8-row float32 tiles of wide rows */
+    TAHOE_FORM_TILERING_WIDE_STREAM = 6,  /* wkey_kernel: rows streamed through LDS as 16-bit keys, lane = tree */
+    TAHOE_FORM_QRING_REGION3 = 7,         /* qring_kernel, 192-row tiles of three 64-row regions (K3) */
+    TAHOE_FORM_QRING_REGION2 = 8,         /* qring_kernel, 128-row tiles of two regions */
+    TAHOE_FORM_QRING_REGION_MIXED = 9,    /* whole waves of 192-row tiles + a remainder of 128-row tiles (two launches) */
+    TAHOE_FORM_QRING_SPLIT = 10,          /* small batches: tree slices per tile + ordered_sum_kernel */
+    TAHOE_FORM_QRING_COLUMNS = 11,        /* qring_kernel on 128-slot columns (general node word, or the exchange-bit layout) */
+    TAHOE_FORM_QRING_WIDE = 12,           /* qwide_kernel: 64- / 32- / 16-row tiles, several trees per wave */
+    TAHOE_FORM_QRING_GX = 13,             /* qring_kernel reading codes from L2 (rows too wide for any LDS tile) */
+    TAHOE_FORM_SPARSE_DIRECT = 14,        /* sparse handle: sparse_kernel without a tile */
+    TAHOE_FORM_SPARSE_ROWTILE = 15,       /* sparse_kernel with the 64-row float32 tile */
+    TAHOE_FORM_SPARSE_TOP = 16,           /* sparse_top_kernel */
+    TAHOE_FORM_SPARSE_QRING = 17,         /* sparse_q_kernel */
+    TAHOE_FORM_QRING_REGION8 = 18         /* qring8_kernel: 8-bit rank codes (<= 254 thresholds per feature), 384-row tiles */
+};
+int tahoe_forest_get_kernel_form(const tahoe_forest *f, size_t rows);
+const char *tahoe_kernel_form_name(int form);
 
 /* Kernel timing with hipEvents on the stream the kernel runs on.  set_profiling(f, n) arms up to n
  * launches (0 disarms): each following predict brackets its traversal kernel with an event pair (a pre-pass kernel, if
@@ -346,6 +388,9 @@ tahoe_status tahoe_device_lds_bytes(int *bytes);  /* sharedMemPerBlock analogue,
 tahoe_status tahoe_compare_device(const float *a_dev, const float *b_dev, size_t n, float tol,
                                   size_t *num_bad, void *stream);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -75,7 +75,6 @@ class ForestInfo(C.Structure):
         ("bits_bytes", C.c_int),
         ("lds_levels", C.c_int),
         ("device_bytes", C.c_size_t),
-        ("path_len_sum", C.c_size_t),
         ("lds_bytes_per_block", C.c_int),
         ("device_id", C.c_int),
         ("num_cus", C.c_int),
@@ -93,6 +92,7 @@ class ForestInfo(C.Structure):
         ("relayout_swaps", C.c_size_t),
         ("stream_slots", C.c_int),
         ("stream_levels", C.c_int),
+        ("stream_key_ties", C.c_float),
     ]
 
 
@@ -134,6 +134,8 @@ _PROTOS = {
     "tahoe_host_alloc": (_i, [C.POINTER(_vp), _sz]),
     "tahoe_host_free": (_i, [_vp]),
     "tahoe_forest_get_info": (_i, [_vp, C.POINTER(ForestInfo)]),
+    "tahoe_forest_get_kernel_form": (_i, [_vp, _sz]),
+    "tahoe_kernel_form_name": (C.c_char_p, [_i]),
     "tahoe_forest_set_profiling": (_i, [_vp, _i]),
     "tahoe_forest_kernel_times": (_i, [_vp, _vp, _i, C.POINTER(_i)]),
     "tahoe_forest_prepass_times": (_i, [_vp, _vp, _i, C.POINTER(_i)]),
@@ -421,6 +423,10 @@ class Forest:
 
     def get_strategy(self, rows: int) -> int:
         return lib.tahoe_forest_get_strategy(self._h, rows)
+
+    def kernel_form(self, rows: int) -> str:
+        """Name of the kernel form a predict of `rows` rows launches (TAHOE_FORM_*, include/tahoe_amd.h)."""
+        return lib.tahoe_kernel_form_name(lib.tahoe_forest_get_kernel_form(self._h, rows)).decode()
 
     def reserve(self, rows: int) -> None:
         _check(lib.tahoe_forest_reserve(self._h, rows), "tahoe_forest_reserve")

@@ -1158,7 +1158,7 @@ tahoe_status tahoe_forest_create_ex(tahoe_forest **out, const tahoe_dense_node *
         }
     }
     if (tilering_rows(f) == 0 && tileblock_rows(f) == 0) {  // no 64-row float32 tile kernel for this shape: the wide-row form
-        const tahoe_status ws = widef_build(f, h_inner, h_leaf);
+        const tahoe_status ws = widef_build(f, h_inner, h_real, h_leaf);
         if (ws != TAHOE_OK) {
             tahoe_forest_destroy(f);
             return ws;
@@ -1296,6 +1296,40 @@ tahoe_status tahoe_forest_check(tahoe_forest *f, void *stream)
 
 int tahoe_forest_get_strategy(const tahoe_forest *f, size_t rows) { return f ? resolve_strategy(f, rows) : -1; }
 
+int tahoe_forest_get_kernel_form(const tahoe_forest *f, size_t rows)
+{
+    if (!f) return -1;
+    const int strategy = resolve_strategy(f, rows);
+    if (f->sp) {
+        switch (strategy) {
+        case TAHOE_STRATEGY_QRING: return TAHOE_FORM_SPARSE_QRING;
+        case TAHOE_STRATEGY_TILEBLOCK: return TAHOE_FORM_SPARSE_TOP;
+        case TAHOE_STRATEGY_ROWTILE: return TAHOE_FORM_SPARSE_ROWTILE;
+        default: return TAHOE_FORM_SPARSE_DIRECT;
+        }
+    }
+    switch (strategy) {
+    case TAHOE_STRATEGY_QRING: return qring_form(f, rows);
+    case TAHOE_STRATEGY_TILERING:
+        if (tilering_rows(f) > 0) return TAHOE_FORM_TILERING_TILE;
+        if (widef_rows(f) > 0) return widef_stream_slots(f) > 0 ? TAHOE_FORM_TILERING_WIDE_STREAM : TAHOE_FORM_TILERING_WIDE_TILE;
+        return TAHOE_FORM_NONE;
+    case TAHOE_STRATEGY_TILEBLOCK: return tileblock_rows(f) > 0 ? TAHOE_FORM_TILEBLOCK : TAHOE_FORM_NONE;
+    case TAHOE_STRATEGY_ROWTILE: return rowtile_fits(f) ? TAHOE_FORM_ROWTILE : TAHOE_FORM_NONE;
+    case TAHOE_STRATEGY_DIRECT: return TAHOE_FORM_DIRECT;
+    default: return TAHOE_FORM_NONE;
+    }
+}
+
+const char *tahoe_kernel_form_name(int form)
+{
+    static const char *const names[] = {"none", "direct", "rowtile", "tileblock", "tilering_tile", "tilering_wide_tile",
+                                        "tilering_wide_stream", "qring_region3", "qring_region2", "qring_region_mixed",
+                                        "qring_split", "qring_columns", "qring_wide", "qring_gx", "sparse_direct",
+                                        "sparse_rowtile", "sparse_top", "sparse_qring", "qring_region8"};
+    return form >= 0 && form < (int)(sizeof(names) / sizeof(names[0])) ? names[form] : "?";
+}
+
 tahoe_status tahoe_forest_get_info(const tahoe_forest *f, tahoe_forest_info *info)
 {
     if (!f || !info) return fail(TAHOE_ERR_INVALID_ARG, "null argument");
@@ -1330,6 +1364,7 @@ tahoe_status tahoe_forest_get_info(const tahoe_forest *f, tahoe_forest_info *inf
     info->tilering_lds_bytes = tilering_rows(f) ? (int)tilering_lds_bytes(f, info->ring_rows) : (int)widef_lds_bytes(f);
     info->stream_slots = widef_stream_slots(f);
     info->stream_levels = widef_stream_levels(f);
+    info->stream_key_ties = widef_stream_tie_estimate(f);
     info->qring_tile_rows = info->qring_walkers == 0 ? 0 : qwide_rows(f) ? qwide_rows(f) : qring_regions(f) ? 192 : qring_lds_tile(f) ? 128 : 0;
     info->relayout = f->relayout ? 1 : 0;
     info->relayout_swaps = f->relayout_swaps;

@@ -152,6 +152,7 @@ int qwide_chains(const tahoe_forest *f); // ... and the trees a lane walks at on
 bool qring_lds_tile(const tahoe_forest *f);
 bool qring_regions(const tahoe_forest *f);  // region form: tiles of 192 (or 128) rows as 64-row regions
 int qring_groups(const tahoe_forest *f);  // tree groups with separate quantisation (1 for most forests)
+int qring_form(const tahoe_forest *f, size_t rows);  // TAHOE_FORM_* of the launch for a batch of `rows` rows
 
 // sparse forests (sparse.hip)
 bool sparse_tile_fits(const tahoe_forest *f);
@@ -162,11 +163,13 @@ bool sparse_q_available(const tahoe_forest *f);  // the walk on quantised codes 
 void sparse_destroy(tahoe_forest *f);
 void pipeline_destroy(tahoe_forest *f);
 // TILERING for rows too wide for a 64-row float32 tile (widef.hip)
-tahoe_status widef_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner, const std::vector<float> &h_leaf);
+tahoe_status widef_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner, const std::vector<unsigned char> &h_real,
+                         const std::vector<float> &h_leaf);
 int widef_rows(const tahoe_forest *f);  // rows per tile; 0 = unavailable
 long long widef_lds_bytes(const tahoe_forest *f);   // LDS per workgroup of the form the launch takes
 int widef_stream_slots(const tahoe_forest *f);      // row slots of the row-streaming form; 0 = the tile form runs
 int widef_stream_levels(const tahoe_forest *f);     // ... and the levels of all trees it keeps in LDS
+float widef_stream_tie_estimate(const tahoe_forest *f);  // estimated share of key compares that tie (0 when the form was never sized)
 tahoe_status widef_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, const float *data, size_t rows, hipStream_t stream,
                           const float *sums_in);
 void widef_destroy(tahoe_forest *f);

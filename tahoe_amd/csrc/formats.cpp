@@ -412,7 +412,7 @@ static_assert(sizeof(BinHeader) == 64, "BinHeader is the on-disk layout");
 constexpr uint32_t kBinVersion = 1;
 
 // four independent multiply-add lanes over 64-bit words, folded; the tail bytes are zero-extended
-uint64_t payload_checksum(const void *p, size_t n)
+static uint64_t payload_checksum(const void *p, size_t n)
 {
     const uint64_t K = 0x9E3779B97F4A7C15ull;
     uint64_t h[4] = {1, 2, 3, 4};
@@ -431,7 +431,7 @@ uint64_t payload_checksum(const void *p, size_t n)
     return r ^ (r >> 32);
 }
 
-tahoe_status write_bin(const char *path, uint32_t kind, int a, int b, float missing, const void *payload, size_t bytes,
+static tahoe_status write_bin(const char *path, uint32_t kind, int a, int b, float missing, const void *payload, size_t bytes,
                        int64_t src_size, int64_t src_mtime_ns)
 {
     BinHeader h;
@@ -460,7 +460,7 @@ tahoe_status write_bin(const char *path, uint32_t kind, int a, int b, float miss
 }
 
 // Reads and validates; *payload is malloc'ed.  want_src_*: when non-zero the header must name that text file state.
-tahoe_status read_bin(const char *path, uint32_t kind, BinHeader *h, void **payload, size_t elem_bytes)
+static tahoe_status read_bin(const char *path, uint32_t kind, BinHeader *h, void **payload, size_t elem_bytes)
 {
     FILE *fp = fopen(path, "rb");
     if (!fp) return fail(TAHOE_ERR_IO, "fail to read: %s: %s", path, strerror(errno));
@@ -507,7 +507,7 @@ tahoe_status read_bin(const char *path, uint32_t kind, BinHeader *h, void **payl
     return TAHOE_OK;
 }
 
-bool stat_source(const char *path, int64_t *size, int64_t *mtime_ns)
+static bool stat_source(const char *path, int64_t *size, int64_t *mtime_ns)
 {
     struct stat st;
     if (stat(path, &st) != 0) return false;

@@ -1116,4 +1116,21 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
     return TAHOE_OK;
 }
 
+// The form qring_launch takes for a batch of `rows` rows (TAHOE_FORM_*): the same decisions, nothing launched.
+int qring_form(const tahoe_forest *f, size_t rows)
+{
+    const tahoe_qstate *q = f->q;
+    if (!q || qring_walkers(f) == 0) return TAHOE_FORM_NONE;
+    if (qwide_rows(f)) return TAHOE_FORM_QRING_WIDE;
+    if (!qring_lds_tile(f)) return TAHOE_FORM_QRING_GX;
+    if (!q->reg) return TAHOE_FORM_QRING_COLUMNS;
+    int most = 1;
+    if (q_slices(f, rows, &most) > 1) return TAHOE_FORM_QRING_SPLIT;
+    size_t rows3 = 0;
+    int chains = 2;
+    qreg_plan(rows, f->num_cus, f->knob_qring_chains, &rows3, &chains);
+    if (rows3 > 0 && chains == 2) return TAHOE_FORM_QRING_REGION_MIXED;
+    return chains == 3 ? TAHOE_FORM_QRING_REGION3 : TAHOE_FORM_QRING_REGION2;
+}
+
 }  // namespace tahoe

@@ -257,6 +257,7 @@ static long long wf_lds(int cols, int rt, int nwalk, int lw)
 int widef_rows(const tahoe_forest *f) { return f->wf ? f->wf->rt : 0; }
 int widef_stream_slots(const tahoe_forest *f) { return f->wf && f->wf->s_on ? f->wf->s_slots : 0; }
 int widef_stream_levels(const tahoe_forest *f) { return f->wf && f->wf->s_on ? f->wf->s_lw : 0; }
+float widef_stream_tie_estimate(const tahoe_forest *f) { return f->wf ? f->wf->key_tie_estimate : 0.f; }
 long long widef_lds_bytes(const tahoe_forest *f)
 {
     const tahoe_wstate *w = f->wf;
@@ -286,7 +287,8 @@ static hipError_t wf_allow(int limit)
 
 // Builds the tops and blocks of the wide float32 form when it is the only float32 tile kernel this shape can have (the caller
 // checks that).  Leaves f->wf null (TAHOE_OK) when no tile of >= 8 rows fits LDS beside the walkers' slots.
-tahoe_status widef_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner, const std::vector<float> &h_leaf)
+tahoe_status widef_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner, const std::vector<unsigned char> &h_real,
+                         const std::vector<float> &h_leaf)
 {
     const int cols = f->p.num_cols, De = f->depth;
     const size_t T = (size_t)f->p.num_trees;
@@ -361,7 +363,7 @@ tahoe_status widef_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner,
         : rt == 16 ? (nwalk == 15 ? wf_allow<16, 15>(f->lds_limit) : wf_allow<16, 12>(f->lds_limit))
                    : (nwalk == 15 ? wf_allow<8, 15>(f->lds_limit) : wf_allow<8, 12>(f->lds_limit));
     if (e != hipSuccess) return bad("hipFuncSetAttribute");
-    return wkey_build(f, h_inner, h_leaf);  // the row-streaming form on 16-bit keys (wkey.hip), where it applies
+    return wkey_build(f, h_inner, h_real, h_leaf);  // the row-streaming form on 16-bit keys (wkey.hip), where it applies
 }
 
 template <int RT, int NWALK>

@@ -18,12 +18,14 @@ struct tahoe_wstate {
     size_t leaf_rows = 0;
     size_t slab_bytes = 0;          // cap of the workspace: larger batches are walked in slabs of rows
     float key_lo = 0.f, key_scale = 0.f;  // key(x) = trunc(clamp((x - key_lo) * key_scale, 0, 65534))
+    float key_tie_estimate = 0.f;   // estimated share of compares whose keys tie (wkey_build); the form is taken only below kWkTieLimit
     bool s_on = false;              // the launch takes it
 };
 
 namespace tahoe {
 
-tahoe_status wkey_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner, const std::vector<float> &h_leaf);
+tahoe_status wkey_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner, const std::vector<unsigned char> &h_real,
+                        const std::vector<float> &h_leaf);
 void wkey_free(tahoe_wstate *w);
 long long wkey_lds_bytes(const tahoe_forest *f);
 tahoe_status wkey_reserve(tahoe_forest *f, size_t rows);  // the leaf-value workspace for batches of up to `rows` rows

@@ -48,6 +48,11 @@
 
 #include "widef_internal.h"
 
+// The 16-byte LDS-DMA (global_load_lds_dwordx4) of the image load exists on gfx950 only; nothing here has a fallback.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "wkey.hip is written for gfx950 (CDNA4): global_load_lds with 16-byte pieces, 160 KiB of LDS per workgroup"
+#endif
+
 namespace tahoe {
 
 #ifndef TAHOE_WK_LOADERS
@@ -65,6 +70,9 @@ constexpr int kWkSumRows = 64;                // rows the summer wave adds at on
 constexpr int kWkChains = TAHOE_WK_CHAINS;  // 64-tree chunks of one row a walker wave walks at once (chains per lane; 3: 0.63 ms, 4: 0.61)
 constexpr int kWkSpinLimit = 1 << 22;
 constexpr uint32_t kWkMissing = 0xFFFFu;
+// Largest estimated share of compares with equal keys at which the create-time rule still takes this form (K2's uniform
+// thresholds: 1.6e-5, i.e. 0.1 % of the wave-levels on the float32 path; 1e-4 is ~0.6 % of them).
+constexpr float kWkTieLimit = 1.0e-4f;
 
 // Timing-only ablation builds (make ABLATE=n; results are wrong on purpose; never shipped): 1 = no bottom-block gathers,
 // 2 = walkers only pass the rows on, 3 = the loaders load nothing, 4 = the summer adds nothing; 5 = 2 + 4 (loaders alone),
@@ -115,7 +123,7 @@ __device__ __forceinline__ uint32_t wk_descend(uint32_t p, uint64_t right_mask)
 template <int TSL, bool WRITE_LEAF>
 __global__ void __launch_bounds__((kWkLoaders + 1 + kWkWalkers) * 64)
     wkey_kernel(const float *__restrict__ data, const unsigned char *__restrict__ kimg, const uint4 *__restrict__ kblocks,
-                const InnerNode *__restrict__ inner, const uint32_t *__restrict__ leaf_orig, float *__restrict__ leafbuf,
+                const InnerNode *__restrict__ inner, const uint32_t *__restrict__ leaf_orig, float *leafbuf,
                 float *sums, const float *sums_in, uint32_t *__restrict__ leaf_out, size_t rows, int cols, int num_trees, int depth, int lw,
                 int img_bytes, int S, float missing, float key_lo, float key_scale, int *__restrict__ error_flag)
 {
@@ -131,6 +139,7 @@ __global__ void __launch_bounds__((kWkLoaders + 1 + kWkWalkers) * 64)
     uint32_t *walked = row_ready + S;                                                    // [S] items walked in the slot, monotone
     uint32_t *row_ms = walked + S;                                                       // [S] != 0: the row has a missing value
     uint32_t *prog = row_ms + S;  // [kWkWalkers] items of walker w whose leaf values have reached the workspace (stores complete)
+    uint32_t *abort_flag = prog + kWkWalkers;  // != 0: a wave of this workgroup gave up (error_flag is raised): everyone leaves at once
     const size_t per = (rows + gridDim.x - 1) / gridDim.x;
     const size_t r0 = (size_t)blockIdx.x * per;
     if (r0 >= rows) return;
@@ -141,6 +150,7 @@ __global__ void __launch_bounds__((kWkLoaders + 1 + kWkWalkers) * 64)
     // ---- the resident tops: the image lies in global memory exactly as in LDS (LDS-DMA: 1 KiB per wave-instruction) ----
     for (int pc = wave; pc < (img_bytes >> 10); pc += NW) wk_dma16(kimg + (size_t)pc * 1024 + lane * 16, smem + (size_t)pc * 1024);
     if (tid < kWkWalkers) prog[tid] = 0u;
+    if (tid == kWkWalkers) *abort_flag = 0u;
     if (tid < S) {
         row_ready[tid] = 0u;
         walked[tid] = 0u;
@@ -210,7 +220,7 @@ __global__ void __launch_bounds__((kWkLoaders + 1 + kWkWalkers) * 64)
                 const uint32_t need = (uint32_t)nit * (uint32_t)(k / S);
                 int spins = 0;
                 while (lds_flag_load(&walked[slot]) < need) {
-                    if (++spins > kWkSpinLimit) {
+                    if (++spins > kWkSpinLimit || lds_flag_load(abort_flag) != 0u) {
                         dead = true;
                         break;
                     }
@@ -227,7 +237,10 @@ __global__ void __launch_bounds__((kWkLoaders + 1 + kWkWalkers) * 64)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the keys are in LDS
             if (lane == 0) lds_flag_store(&row_ready[slot], (uint32_t)(k + 1));
         }
-        if (dead && lane == 0) atomicOr(error_flag, 1);
+        if (dead && lane == 0) {
+            lds_flag_store(abort_flag, 1u);
+            atomicOr(error_flag, 1);
+        }
         return;
     }
 
@@ -247,13 +260,23 @@ __global__ void __launch_bounds__((kWkLoaders + 1 + kWkWalkers) * 64)
             for (;;) {
                 const bool ok = lds_flag_load(&prog[w]) >= need;
                 if (__ballot(ok) == ~0ull) break;
-                if (++spins > kWkSpinLimit) {
+                if (++spins > kWkSpinLimit || lds_flag_load(abort_flag) != 0u) {
                     dead = true;
                     break;
                 }
                 __builtin_amdgcn_s_sleep(8);
             }
             if (dead) break;
+            // Hand-over through global memory INSIDE one workgroup: a walker stores its leaf values, executes a workgroup-scope
+            // release fence (s_waitcnt vmcnt(0): the stores are complete, i.e. written through this CU's L1 to L2), then raises
+            // prog[]; this wave reads prog[], executes the workgroup-scope acquire fence below, then loads.  What makes that
+            // sufficient is the memory model of the target, not the access history: the waves of a workgroup run on one CU and
+            // share its vector L1 (the library is never built in threadgroup-split mode), so a line one of them wrote cannot be
+            // stale for another -- LLVM's AMDGPU memory model needs no cache invalidation for workgroup scope for exactly that
+            // reason, and the fence builtin emits whatever the compile target does need.  It also keeps the compiler from
+            // moving or merging the loads below across the flag loads (the former code relied on LLVM not speculating them).
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            TAHOE_LDS_ACQUIRE();
             const int k = g0 + lane;
             if (k < g1) {
                 const float *v = leafbuf + (r0 + k) * (size_t)tv;
@@ -276,7 +299,10 @@ __global__ void __launch_bounds__((kWkLoaders + 1 + kWkWalkers) * 64)
                 sums[r0 + k] = sum;
             }
         }
-        if (dead && lane == 0) atomicOr(error_flag, 1);
+        if (dead && lane == 0) {
+            lds_flag_store(abort_flag, 1u);
+            atomicOr(error_flag, 1);
+        }
         return;
     }
 
@@ -286,7 +312,10 @@ __global__ void __launch_bounds__((kWkLoaders + 1 + kWkWalkers) * 64)
     const uint32_t n_blocks = 1u << (depth - 2);
     const uint32_t first_block_node = n_blocks - 1;
     if (wk_lds_addr(smem) != 0u) {  // the integer LDS addresses below take the tops at LDS address 0 (true without static LDS)
-        if (lane == 0) atomicOr(error_flag, 2);
+        if (lane == 0) {
+            lds_flag_store(abort_flag, 1u);  // loaders and summer leave at once instead of waiting out their spin limits
+            atomicOr(error_flag, 2);
+        }
         return;
     }
     const uint32_t xbase0 = (uint32_t)img_bytes;
@@ -433,7 +462,7 @@ __global__ void __launch_bounds__((kWkLoaders + 1 + kWkWalkers) * 64)
         {   // the row's keys are in LDS
             int spins = 0;
             while (lds_flag_load(&row_ready[slot]) != (uint32_t)(k + 1)) {
-                if (++spins > kWkSpinLimit) {
+                if (++spins > kWkSpinLimit || lds_flag_load(abort_flag) != 0u) {
                     dead = true;
                     break;
                 }
@@ -443,7 +472,7 @@ __global__ void __launch_bounds__((kWkLoaders + 1 + kWkWalkers) * 64)
             TAHOE_LDS_ACQUIRE();
         }
         if (leafbuf && items_done != 0u) {  // the previous item's leaf values have reached the workspace: tell the summer
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // s_waitcnt vmcnt(0): the stores are complete before the flag
             if (lane == 0) lds_flag_store(&prog[wid], items_done);
         }
         if (lds_flag_load(&row_ms[slot]) != 0u)
@@ -460,10 +489,13 @@ __global__ void __launch_bounds__((kWkLoaders + 1 + kWkWalkers) * 64)
         }
     }
     if (leafbuf) {  // the last item's leaf values; a walker that never had an item reports what the summer expects of it: nothing
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) lds_flag_store(&prog[wid], items_done);
     }
-    if (dead && lane == 0) atomicOr(error_flag, 1);
+    if (dead && lane == 0) {
+        lds_flag_store(abort_flag, 1u);
+        atomicOr(error_flag, 1);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -499,7 +531,8 @@ static uint32_t wk_node_word(const InnerNode &nd, uint16_t key)
 // Builds the image of the tops and the 32-byte bottom blocks when the shape suits the form: rows of 16-byte multiples, feature
 // ids of 15 bits, and LDS for the tops of all trees down to the bottom blocks (levels in between would be walked on float32
 // values from global memory: correct, tested with TAHOE_WSTREAM=1, but slower than the tile form) beside >= kWkLoaders row slots.
-tahoe_status wkey_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner, const std::vector<float> &h_leaf)
+tahoe_status wkey_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner, const std::vector<unsigned char> &h_real,
+                        const std::vector<float> &h_leaf)
 {
     tahoe_wstate *w = f->wf;
     if (!w) return TAHOE_OK;
@@ -523,15 +556,18 @@ tahoe_status wkey_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner, 
     while (slots < 16 && wk_lds(cols, (int)T, s_lw, s_ts, slots + 1) <= f->lds_limit) ++slots;
     hipError_t e;
     auto bad = [&](const char *what) { return fail(TAHOE_ERR_HIP, "wkey_build: %s failed: %s", what, hipGetErrorString(e)); };
-    // ---- the key map: [lo, hi] = range of the finite thresholds; their keys from the device ----
+    // ---- the key map: [lo, hi] = range of the finite thresholds of the nodes that exist (the padding below an early leaf
+    // carries thr = 0.0 and decides nothing: it neither stretches the range nor ever ties, see below); keys from the device ----
     float lo = 0.f, hi = 0.f;
     bool any = false;
-    for (const InnerNode &nd : h_inner)
-        if (std::isfinite(nd.thr)) {
+    for (size_t i = 0; i < h_inner.size(); ++i) {
+        const InnerNode &nd = h_inner[i];
+        if (h_real[i] && std::isfinite(nd.thr)) {
             lo = any ? std::min(lo, nd.thr) : nd.thr;
             hi = any ? std::max(hi, nd.thr) : nd.thr;
             any = true;
         }
+    }
     float scale = (any && hi > lo) ? 65534.0f / (hi - lo) : 0.f;
     if (!std::isfinite(scale)) scale = 0.f;  // (everything then ties and is decided on the float32 values: slow, correct)
     std::vector<uint16_t> h_keys(h_inner.size());
@@ -557,6 +593,46 @@ tahoe_status wkey_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner, 
         (void)hipFree(d_keys);
         if (e != hipSuccess) return bad("threshold keys");
     }
+    // Padding below an early leaf: both subtrees are the same leaf, so the branch is irrelevant -- key 0xFFFF never compares
+    // greater and never ties (a missing x, the only other 0xFFFF, is taken out of the tie mask by the missing rule).
+    for (size_t i = 0; i < h_inner.size(); ++i)
+        if (!h_real[i]) h_keys[i] = (uint16_t)kWkMissing;
+    // ---- how fine is ONE affine map for this forest?  A compare costs two divergent global loads when the feature's key
+    // equals the threshold's (8 % of the wave-levels on that path cost 41 % of the texture path's time, header).  With one
+    // [lo, hi] for all features, a feature whose thresholds span few key cells -- a small-scale feature beside a large-scale
+    // one, or any forest with one outlier threshold -- ties often: if its values spread like its thresholds, a compare ties
+    // with probability ~ 1 / (cells its thresholds span).  Estimate: that quantity per node, weighted by the node's reach
+    // probability 2^-level, over the features that have at least two distinct keys.  Above kWkTieLimit the tile form
+    // (widef.hip) serves TILERING instead; TAHOE_WSTREAM=1 still forces this form (tests), results are exact either way.
+    {
+        std::vector<uint32_t> kmin((size_t)cols, 0xFFFFu), kmax((size_t)cols, 0u);
+        std::vector<float> tmin((size_t)cols, INFINITY), tmax((size_t)cols, -INFINITY);
+        for (size_t i = 0; i < h_inner.size(); ++i) {
+            if (!h_real[i] || !std::isfinite(h_inner[i].thr)) continue;
+            const size_t fid = h_inner[i].meta & kMetaFidMask;
+            if (fid >= (size_t)cols) continue;
+            kmin[fid] = std::min<uint32_t>(kmin[fid], h_keys[i]);
+            kmax[fid] = std::max<uint32_t>(kmax[fid], h_keys[i]);
+            tmin[fid] = std::min(tmin[fid], h_inner[i].thr);
+            tmax[fid] = std::max(tmax[fid], h_inner[i].thr);
+        }
+        double num = 0.0, den = 0.0;
+        for (size_t t = 0; t < T; ++t)
+            for (size_t i = 0; i < n_inner; ++i) {
+                const size_t at = t * n_inner + i;
+                if (!h_real[at] || !std::isfinite(h_inner[at].thr)) continue;
+                const size_t fid = h_inner[at].meta & kMetaFidMask;
+                if (fid >= (size_t)cols || !(tmax[fid] > tmin[fid])) continue;  // one distinct threshold: nothing to judge the scale by
+                int level = 0;
+                for (size_t v = i + 1; v > 1; v >>= 1) ++level;
+                const double wgt = std::ldexp(1.0, -level);
+                // (distinct thresholds that collapse into one key cell: every compare of that feature ties)
+                num += wgt / (double)std::max<uint32_t>(kmax[fid] - kmin[fid], 1u);
+                den += wgt;
+            }
+        w->key_tie_estimate = den > 0.0 ? (float)(num / den) : (scale > 0.f ? 0.f : 1.f);
+    }
+    if (knob != 1 && w->key_tie_estimate > kWkTieLimit) return TAHOE_OK;  // s_on stays false: the tile form runs
     const size_t nlv = ((size_t)1 << s_lw) - 1;
     const size_t img = (size_t)wk_img_bytes(s_lw, s_ts);
     std::vector<uint32_t> h_img(img / 4, 0u);

@@ -40,6 +40,16 @@ static void die(const char *what)
         if ((call) != TAHOE_OK) die(#call); \
     } while (0)
 
+// every RCCL call is checked: a failed collective ends the run with its own message, not with "Results are incorrect"
+#define NCCL_OK(call)                                                                   \
+    do {                                                                                \
+        const ncclResult_t r__ = (call);                                                \
+        if (r__ != ncclSuccess) {                                                       \
+            fprintf(stderr, "%s: %s (%s:%d)\n", #call, ncclGetErrorString(r__), __FILE__, __LINE__); \
+            exit(1);                                                                    \
+        }                                                                               \
+    } while (0)
+
 static float cpu_tree(const tahoe_dense_node *root, const float *row, float missing)
 {
     int at = 0;
@@ -140,17 +150,19 @@ int main(int argc, char **argv)
     std::vector<ncclComm_t> comms((size_t)G);
     const bool use_rccl = !emulate && !chain && !by_rows;
     if (use_rccl) {
-        const ncclResult_t r = ncclCommInitAll(comms.data(), G, devs.data());
-        if (r != ncclSuccess) {
-            fprintf(stderr, "ncclCommInitAll: %s\n", ncclGetErrorString(r));
-            return 1;
+        NCCL_OK(ncclCommInitAll(comms.data(), G, devs.data()));
+        for (int g = 0; g < G; ++g) {  // every communicator knows its size, rank and device
+            int count = 0, rank_of = -1, dev_of = -1;
+            NCCL_OK(ncclCommCount(comms[(size_t)g], &count));
+            NCCL_OK(ncclCommUserRank(comms[(size_t)g], &rank_of));
+            NCCL_OK(ncclCommCuDevice(comms[(size_t)g], &dev_of));
+            if (count != G || rank_of != g || dev_of != devs[(size_t)g]) {
+                fprintf(stderr, "RCCL communicator %d: count %d (expected %d), rank %d, device %d (expected %d)\n", g, count, G, rank_of, dev_of,
+                        devs[(size_t)g]);
+                return 1;
+            }
         }
-        int count = 0;
-        if (ncclCommCount(comms[0], &count) != ncclSuccess || count != G) {
-            fprintf(stderr, "ncclCommCount = %d, expected %d\n", count, G);
-            return 1;
-        }
-        printf("RCCL communicator of %d rank(s)\n", count);
+        printf("RCCL communicator of %d rank(s)\n", G);
     }
     // chain: one event per (device, chunk)
     const size_t n_chunks = chain ? (rows + chunk - 1) / chunk : 0;
@@ -206,16 +218,16 @@ int main(int argc, char **argv)
             if (wide) OK(tahoe_widen_f32_to_f64(wide_d[(size_t)g], sums_d[(size_t)g], rows, stream[(size_t)g]));
         }
         if (use_rccl) {
-            ncclGroupStart();
+            NCCL_OK(ncclGroupStart());
             for (int g = 0; g < G; ++g) {
                 if (wide)
-                    ncclAllReduce(wide_d[(size_t)g], wide_d[(size_t)g], rows, ncclFloat64, ncclSum, comms[(size_t)g],
-                                  (hipStream_t)stream[(size_t)g]);
+                    NCCL_OK(ncclAllReduce(wide_d[(size_t)g], wide_d[(size_t)g], rows, ncclFloat64, ncclSum, comms[(size_t)g],
+                                          (hipStream_t)stream[(size_t)g]));
                 else
-                    ncclAllReduce(sums_d[(size_t)g], sums_d[(size_t)g], rows, ncclFloat32, ncclSum, comms[(size_t)g],
-                                  (hipStream_t)stream[(size_t)g]);
+                    NCCL_OK(ncclAllReduce(sums_d[(size_t)g], sums_d[(size_t)g], rows, ncclFloat32, ncclSum, comms[(size_t)g],
+                                          (hipStream_t)stream[(size_t)g]));
             }
-            ncclGroupEnd();
+            NCCL_OK(ncclGroupEnd());
             if (wide)
                 for (int g = 0; g < G; ++g) {
                     OK(tahoe_device_set(devs[(size_t)g]));
@@ -233,6 +245,12 @@ int main(int argc, char **argv)
     gettimeofday(&t1, NULL);
     const double us = ((t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_usec - t0.tv_usec)) / reps;
     for (int g = 0; g < G; ++g) OK(tahoe_forest_check(shard[(size_t)g], stream[(size_t)g]));
+    if (use_rccl)  // an asynchronous failure of a collective (a peer lost, a link error) shows here, not in the sums
+        for (int g = 0; g < G; ++g) {
+            ncclResult_t async = ncclSuccess;
+            NCCL_OK(ncclCommGetAsyncError(comms[(size_t)g], &async));
+            NCCL_OK(async);
+        }
 
     std::vector<float> total(rows, 0.f), part(rows);
     if (by_rows) {  // every device holds the finished sums of its rows
@@ -303,7 +321,7 @@ int main(int argc, char **argv)
     printf(bad == 0 ? "Results are correct\n" : "Results are incorrect\n");
     for (int g = 0; g < G; ++g) {
         OK(tahoe_device_set(devs[(size_t)g]));
-        if (use_rccl) ncclCommDestroy(comms[(size_t)g]);
+        if (use_rccl) NCCL_OK(ncclCommDestroy(comms[(size_t)g]));
         for (void *e : done[(size_t)g]) tahoe_event_destroy(e);
         for (void *e : taken[(size_t)g]) tahoe_event_destroy(e);
         tahoe_forest_destroy(shard[(size_t)g]);

@@ -34,7 +34,29 @@ def test_library_exports_every_declared_symbol(ta):
     assert not missing, f"declared in include/tahoe_amd.h but not exported: {missing}"
     # and the ctypes binding covers the header exactly
     assert sorted(ta.capi.EXPORTED_SYMBOLS) == syms
-    assert ta.lib.tahoe_abi_version() == 1
+    assert ta.lib.tahoe_abi_version() == 2
+
+
+def test_library_exports_nothing_but_the_abi(ta):
+    """The boundary promises plain C entry points and nothing else (include/tahoe_amd.h:1-32): no C++ internals, no
+    kernel stubs, no unprefixed helpers -- `nm -D --defined-only` lists exactly the header's declarations."""
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", "--defined-only", ta.capi.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    names = [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
+    # (the version node of the linker script shows as an absolute symbol: `A TAHOE_AMD_2`)
+    exported = sorted(n.split("@")[0] for n in names if not n.startswith("TAHOE_AMD_"))
+    assert exported == header_symbols(), sorted(set(exported) ^ set(header_symbols()))
+
+
+def test_kernel_form_names_cover_the_enum(ta):
+    text = open(os.path.join(ROOT, "include", "tahoe_amd.h")).read()
+    forms = dict((int(v), k) for k, v in re.findall(r"TAHOE_FORM_([A-Z0-9_]+) = (\d+)", text))
+    assert sorted(forms) == list(range(len(forms)))
+    for value, name in forms.items():
+        assert ta.lib.tahoe_kernel_form_name(value).decode() == name.lower()
+    assert ta.lib.tahoe_kernel_form_name(len(forms)).decode() == "?" and ta.lib.tahoe_kernel_form_name(-1).decode() == "?"
+    assert ta.lib.tahoe_forest_get_kernel_form(None, 1) == -1
 
 
 def test_node_encoding_matches_reference_masks(ta):

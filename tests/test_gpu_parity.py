@@ -926,3 +926,49 @@ def test_wide_rows_streaming_form_walks_large_batches_in_slabs(env, monkeypatch)
     f.check()
     assert np.array_equal(bits(acc.cpu().numpy()), bits(oracle.predict_continue(nodes, T, D, data, MISSING, start)))
     f.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["two_scales", "one_outlier_threshold", "uniform"])
+def test_wide_rows_form_rule_looks_at_key_resolution(env, monkeypatch, case):
+    """The row-streaming form maps every feature with ONE affine 16-bit key map over the range of all thresholds.  A forest
+    whose features live on different scales (or with one outlier threshold) would tie on most compares of its small-scale
+    features -- bit-exact still, but on the slow float32 path.  The create-time rule estimates that (stream_key_ties) and
+    leaves such forests to the tile form; forced with TAHOE_WSTREAM=1 the streaming form still reproduces the oracle."""
+    ta, oracle, torch = env
+    monkeypatch.delenv("TAHOE_WSTREAM", raising=False)
+    T, D, C, R = 200, 8, 1024, 1500   # 3 T <= C, six resident levels: the shape rule alone would take the streaming form
+    nodes = ta.synth_forest(T, D, C, seed=1201).copy()
+    data = ta.synth_data(R, C, seed=1202, missing_prob=0.01, missing=MISSING)
+    inner = nodes["bits"] >= 0
+    fid = nodes["bits"] & ((1 << 30) - 1)
+    if case == "two_scales":          # odd features: thresholds and values 1000 x larger
+        big = inner & (fid % 2 == 1)
+        nodes["val"][big] *= np.float32(1000.0)
+        keep = (data == np.float32(MISSING))
+        data[:, 1::2] *= np.float32(1000.0)
+        data[keep] = np.float32(MISSING)
+    elif case == "one_outlier_threshold":
+        nodes["val"][np.flatnonzero(inner)[5]] = np.float32(1.0e6)
+    f = ta.Forest(nodes, T, D, C, missing=MISSING)
+    info = f.info()
+    if case == "uniform":
+        assert info.stream_slots >= 4 and info.stream_key_ties < 1e-4 and f.kernel_form(R) != "tilering_wide_tile"
+    else:
+        assert info.stream_slots == 0 and info.stream_key_ties > 1e-4, (info.stream_slots, info.stream_key_ties)
+    f.set_strategy(ta.STRATEGY_TILERING)
+    assert f.kernel_form(R) == ("tilering_wide_stream" if case == "uniform" else "tilering_wide_tile")
+    want, want_leaf = oracle.predict(nodes, T, D, data, MISSING, want_leaf=True, threads=8)
+    x = torch.from_numpy(data).cuda()
+    leaf, sums = f.predict_leaf_idx(x)
+    f.check()
+    assert np.array_equal(bits(leaf.cpu().numpy()), want_leaf) and np.array_equal(bits(sums.cpu().numpy()), bits(want))
+    f.close()
+    monkeypatch.setenv("TAHOE_WSTREAM", "1")     # the streaming form on the poor key map: slow, exact
+    g = ta.Forest(nodes, T, D, C, missing=MISSING)
+    g.set_strategy(ta.STRATEGY_TILERING)
+    assert g.info().stream_slots >= 4 and g.kernel_form(R) == "tilering_wide_stream"
+    leaf, sums = g.predict_leaf_idx(x)
+    g.check()
+    assert np.array_equal(bits(leaf.cpu().numpy()), want_leaf) and np.array_equal(bits(sums.cpu().numpy()), bits(want))
+    g.close()
