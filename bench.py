@@ -41,7 +41,8 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 MISSING = -999.0
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r03")
+PROFILE_ROUND = "r04"
+PROFILE_DIR = os.path.join(ROOT, "profiles", PROFILE_ROUND)
 
 
 def algorithmic_bytes_per_sample(T, depth, cols, bits_bytes):
@@ -81,7 +82,7 @@ def load_profile(name):
 def physical_ceilings(prof, walk_ms, quant_ms, rows, cols):
     """Per-kernel fractions of the ceilings that physically bind, from the PMC counters of the
     profiled run (ratios inside that run) next to the live kernel times of this one."""
-    out = {"source": "profiles/r03/pmc_k3.json", "src_hash": prof["src_hash"]}
+    out = {"source": f"profiles/{PROFILE_ROUND}/pmc_k3.json", "src_hash": prof["src_hash"]}
     for key, kname in (("walk", "qring"), ("quantise", "quantize")):
         parts = [v for n, v in prof["kernels"].items() if kname in n and "bucket_index" not in n]
         if not parts:
@@ -123,6 +124,209 @@ def physical_ceilings(prof, walk_ms, quant_ms, rows, cols):
     return out
 
 
+# ---- the one honest fraction <= 1 the walk has: against the ceiling of the LDS-resident walk itself ----
+def lds_walk_ceiling(walk_ms, rows, trees, depth, num_cus, clock_ghz):
+    """node visits per second of the walk kernel against what tools/ubench_qwalk.hip measures for the LDS-resident part of
+    the same walk alone (14 walker waves x 3 chains, 64-row regions, child pairs by ds_read_b64, no global memory): 7 vector
+    instructions (5 VALU + 2 LDS) per 64-row level, one vector instruction per CU and cycle.  The unit is a "wave-level":
+    one level of the walk for the 64 rows of one wave-chain.  Both times are wall times of whole kernels divided by the
+    wave-levels per CU they contain, so the device clock cancels in `frac`."""
+    wave_levels_per_cu = (rows / 64.0) * trees * depth / max(num_cus, 1)
+    ns_kernel = walk_ms * 1e6 / wave_levels_per_cu
+    out = {"unit": "ns per wave-level (64 rows x one tree level) per CU", "kernel": round(ns_kernel, 4),
+           "kernel_clk_at_device_clock": round(ns_kernel * clock_ghz, 3),
+           "node_visits_per_s": round(rows * trees * depth / (walk_ms * 1e-3), 1),
+           "seven_instruction_floor_clk": 7.0, "frac_of_seven_instruction_floor": round(7.0 / (ns_kernel * clock_ghz), 4)}
+    exe = os.path.join(ROOT, "tools", "ubench_qwalk")
+    ub, source = None, None
+    if os.path.exists(exe):  # live, on this device, as a child process (its own HIP context)
+        import subprocess
+        try:
+            r = subprocess.run([exe, "--kernel-shape"], capture_output=True, text=True, timeout=60)
+            for ln in r.stdout.splitlines():
+                if ln.startswith("{"):
+                    ub = json.loads(ln)
+                    source = "tools/ubench_qwalk --kernel-shape, run live on this device"
+        except (OSError, ValueError, subprocess.SubprocessError):
+            ub = None
+    if ub is None:  # the committed run of the same binary (2.4 GHz assumed in its clk figure)
+        ub = {"ns_per_wave_level_per_cu": 7.71 / 2.4, "nw": 14, "k": 3}
+        source = "profiles/r02/ubench_qwalk.txt (NW 14 K 3 colb 128 pair unrolled: 7.71 clk at 2.4 GHz); live run unavailable"
+    out.update({"ubench": round(ub["ns_per_wave_level_per_cu"], 4), "ubench_shape": f"{ub.get('nw')} walker waves x {ub.get('k')} chains",
+                "ubench_source": source, "frac": round(ub["ns_per_wave_level_per_cu"] / ns_kernel, 4),
+                "frac_means": "time the LDS-resident walk alone needs per wave-level (micro-benchmark, no tops staged, no bottom blocks, "
+                              "no ring) / time the walk kernel takes per wave-level: <= 1 by construction, the share of the kernel's time "
+                              "that its own inner loop accounts for at that loop's measured ceiling"})
+    return out
+
+
+# ---- BASELINE.json's other configurations (K1, K2, K5): workloads as tools/run_configs.py has always built them ----
+BASELINE_SHAPES = {"K1": (500, 8, 18, 10_000, 11, 12, 0.05, 0.02), "K2": (500, 8, 3072, 100_000, 21, 22, 0.0, 0.0),
+                   "K3": (1000, 12, 256, 1_000_000, 42, 43, 0.0, 0.0), "K4": (8000, 12, 256, 1_000_000, 42, 43, 0.0, 0.0)}
+K5_SHAPE = {"trees": 2000, "cols": 256, "rows": 200_000, "min_depth": 4, "max_depth": 24, "leaf_prob": 0.32, "max_tree_nodes": 65535,
+            "forest_seed": 44, "data_seed": 43}
+
+
+def baseline_workload(ta, cfg, through_text_files=False):
+    """(kind, forest description, host rows) of a BASELINE configuration.  kind "dense": (nodes, T, D, C); "sparse": (nodes, trees, C)."""
+    if cfg == "K5":
+        k = K5_SHAPE
+        sn, tr = ta.capi.synth_sparse_forest(k["trees"], k["cols"], k["min_depth"], k["max_depth"], k["leaf_prob"], k["max_tree_nodes"], k["forest_seed"])
+        return "sparse", (sn, tr, k["cols"]), ta.synth_data(k["rows"], k["cols"], seed=k["data_seed"])
+    if cfg == "KR3":  # K3's shape from the histogram-style generator (254 thresholds per feature = LightGBM's max_bin 255): what
+        T, D, C, R = 1000, 12, 256, 1_000_000  # trained models look like
+        nodes = ta.synth_forest_hist(T, D, C, seed=42, feature_seed=7, max_bins=254, zipf_s=1.0, leaf_prob=0.02, scale_decades=3.0)
+        return "dense", (nodes, T, D, C), ta.synth_data_hist(R, C, seed=43, feature_seed=7, scale_decades=3.0)
+    T, D, C, R, fs, ds, lp, mp = BASELINE_SHAPES[cfg]
+    nodes = ta.synth_forest(T, D, C, seed=fs, leaf_prob=lp)
+    data = ta.synth_data(R, C, seed=ds, missing_prob=mp, missing=MISSING)
+    if through_text_files:  # K1: the reference's own file formats (BaseTahoeTest.h:267-402), written and parsed back
+        import tempfile
+        with tempfile.TemporaryDirectory() as d:
+            ta.write_model(os.path.join(d, "m.txt"), nodes, T, D)
+            ta.write_data(os.path.join(d, "d.txt"), data, MISSING)
+            n2, T2, D2 = ta.load_model(os.path.join(d, "m.txt"))
+            x2, miss = ta.load_data(os.path.join(d, "d.txt"))
+        if n2.tobytes() != nodes.tobytes() or x2.tobytes() != data.tobytes() or (T2, D2) != (T, D):
+            raise RuntimeError("text formats did not round-trip")
+        nodes, data = n2, x2
+    return "dense", (nodes, T, D, C), data
+
+
+def config_counters(cfg, ms):
+    """Busy fractions and HBM-side bytes of configuration `cfg` from its stamped counter profile (tools/pmc_script.sh over
+    tools/pmc_target.py), per predict; None when the profile is missing or was taken with other kernel sources."""
+    try:
+        with open(os.path.join(PROFILE_DIR, "pmc_%s.json" % cfg.lower())) as fh:
+            prof = json.load(fh)
+        if prof.get("src_hash") != kernel_source_hash():
+            return None
+        n = int(prof["script"].split()[-1])
+        ks = [v for k, v in prof["kernels"].items() if "bucket_index" not in k]
+        tot = lambda c: sum(v.get(c, 0.0) * v["launches"] for v in ks) / n  # per predict
+        cyc = tot("GRBM_GUI_ACTIVE") / 8.0
+        cus = prof.get("num_cus", 256)
+        vmem = max(tot("SQ_ACTIVE_INST_VMEM"), tot("SQ_INSTS_VMEM_RD"))
+        units = {"vector_issue": (tot("SQ_ACTIVE_INST_VALU") + tot("SQ_ACTIVE_INST_LDS") + vmem) * 4.0 / (cus * 4 * cyc),
+                 "valu": tot("SQ_ACTIVE_INST_VALU") * 4.0 / (cus * 4 * cyc), "lds_array": tot("SQ_LDS_IDX_ACTIVE") / (cus * cyc),
+                 "texture_addr": tot("TA_TA_BUSY") / (cus * cyc), "texture_data": tot("TD_TD_BUSY") / (cus * cyc)}
+        hbm = (tot("FETCH_SIZE") + tot("WRITE_SIZE")) * 1024.0
+        return {"profile": f"profiles/{PROFILE_ROUND}/pmc_{cfg.lower()}.json", "src_hash": prof["src_hash"],
+                "scope": "all kernels of one predict (pre-pass + walk), i.e. step-wide",
+                "kernels_per_predict": round(sum(v["launches"] for v in ks) / n, 2),
+                "kernel_ms_profiled": round(cyc / (prof.get("clock_ghz", 2.4) * 1e6), 4),
+                "hbm_bytes_raw": int(hbm), "hbm_frac_raw": round(hbm / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                "hbm_note": "FETCH_SIZE + WRITE_SIZE, raw (FETCH_SIZE counts half of wide coalesced reads on gfx950)",
+                "l2_to_l1_bytes": int(tot("TCP_TCC_READ_REQ") * 128), "busy": {k: round(v, 3) for k, v in units.items()},
+                "busiest_unit": max(units, key=units.get)}
+    except (OSError, ValueError, KeyError, ZeroDivisionError):
+        return None
+
+
+def config_roofline(ms, rows, cols, trees, len_sum_per_row, node_bytes, n_nodes, cfg, leaf_bytes=None):
+    """SURVEY.md 8(d) for one configuration: the reference's traversal byte model made exact -- per (row, tree) `len` internal
+    visits of one node record (`node_bytes` = 4 + b for the dense SoA format, 12 for sparse_node_t) and one 4-byte feature, plus
+    the leaf record; plus the row once and the prediction -- over the measured time and the HBM peak; the compulsory bytes (rows +
+    forest + predictions once) the same way; the stamped counters of the configuration beside them."""
+    leaf_bytes = node_bytes if leaf_bytes is None else leaf_bytes
+    alg = rows * (len_sum_per_row * (node_bytes + 4) + trees * leaf_bytes + cols * 4 + 4)
+    comp = rows * cols * 4 + n_nodes * node_bytes + rows * 4
+    t = ms * 1e-3
+    return {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "algorithmic_bytes": int(alg), "achieved": round(alg / t / 1e9, 1),
+            "frac": round(alg / t / 1e9 / HBM_PEAK_GBPS, 4), "compulsory_bytes": int(comp),
+            "compulsory_GBps": round(comp / t / 1e9, 1), "compulsory_frac": round(comp / t / 1e9 / HBM_PEAK_GBPS, 5),
+            "mean_path_len": round(len_sum_per_row / trees, 3), "counters": config_counters(cfg, ms)}
+
+
+def dense_path_len_sum(leaf_idx):
+    """Internal nodes visited per (row, tree) = level of the leaf the walk ended on = floor(log2(heap index + 1)); mean row sum."""
+    return float(np.floor(np.log2(leaf_idx.astype(np.float64) + 1.0)).sum(axis=1).mean())
+
+
+def sparse_path_len_sum(sn, tr, want_leaf):
+    """The same for sparse forests: level of every node of every tree (children lie behind their parent), then of each leaf reached."""
+    sizes = np.diff(np.append(tr, sn.size))
+    level = np.zeros(sn.size, dtype=np.int32)
+    frontier = tr.astype(np.int64)
+    root_of = np.repeat(tr.astype(np.int64), sizes)
+    lvl = 0
+    while frontier.size:
+        level[frontier] = lvl
+        inner = frontier[sn["bits"][frontier] >= 0]  # is_leaf is the sign bit
+        kids = root_of[inner] + sn["left_idx"][inner]
+        frontier = np.concatenate([kids, kids + 1])
+        lvl += 1
+    return float(level[tr.astype(np.int64)[None, :] + want_leaf.astype(np.int64)].sum(axis=1).mean())
+
+
+def config_legs(ta, torch, which=("K1", "K2", "K5"), warmup=5, steps=20, check_rows=2048):
+    """BASELINE.json's configurations other than the metric's (K3) and K4, timed on this device after the primary region (never
+    part of `value`): 5 warm-ups + 20 timed predicts with the in-library hipEvents on resident inputs, which kernel form ran,
+    the byte-model and compulsory-byte fractions, the configuration's stamped counters, and a bitwise check of the timed
+    launches' output on >= 2048 rows against the CPU oracle (the checker, called after the timing)."""
+    oracle = _oracle()
+    legs = {}
+    for cfg in which:
+        t_leg = time.perf_counter()
+        try:
+            kind, desc, data = baseline_workload(ta, cfg, through_text_files=(cfg == "K1"))
+            rows, cols = data.shape
+            if kind == "dense":
+                nodes, T, D, C = desc
+                forest = ta.Forest(nodes, T, D, C, missing=MISSING)
+            else:
+                sn, tr, C = desc
+                T = int(tr.size)
+                forest = ta.capi.SparseForest(sn, tr, C, missing=MISSING)
+            forest.reserve(rows)
+            x = torch.from_numpy(data).cuda()
+            out = torch.empty(rows, dtype=torch.float32, device="cuda")
+            for _ in range(warmup):
+                forest.predict_raw(x, out)
+            forest.set_profiling(steps)
+            torch.cuda.synchronize()
+            tw = time.perf_counter()
+            for _ in range(steps):
+                forest.predict_raw(x, out)
+            torch.cuda.synchronize()
+            wall_ms = (time.perf_counter() - tw) / steps * 1e3
+            forest.check()
+            walk, pre = forest.kernel_times_ms(), forest.prepass_times_ms()
+            forest.set_profiling(0)
+            ms = float(np.mean(walk) + (np.mean(pre) if len(pre) else 0.0))
+            info = forest.info()
+            strategy = ta.STRATEGY_NAMES.get(forest.get_strategy(rows), "?")
+            leg = {"workload": (f"{cfg}: {T} trees depth {D}, {cols} features, {rows} rows" if kind == "dense" else
+                                f"{cfg}: sparse forest {T} trees depth {K5_SHAPE['min_depth']}-{K5_SHAPE['max_depth']}, {int(sn.size)} nodes, "
+                                f"{cols} features, {rows} rows") + (", through the text file formats" if cfg == "K1" else ""),
+                   "strategy": ("sparse_" if kind == "sparse" else "") + strategy, "kernel_form": forest.kernel_form(rows),
+                   "ms": round(ms, 4), "ms_source": f"hipEvents inside the library, mean of {len(walk)} predicts (pre-pass + walk)",
+                   "prepass_ms": round(float(np.mean(pre)) if len(pre) else 0.0, 4), "ms_min": round(float(np.min(np.asarray(walk) + np.asarray(pre))), 4),
+                   "wall_ms_per_predict": round(wall_ms, 4), "samples_per_s": round(rows / (ms * 1e-3), 1),
+                   "stream_slots": int(info.stream_slots), "ring_rows": int(info.ring_rows), "qring_tile_rows": int(info.qring_tile_rows)}
+            # ---- the checker: the timed launches' own output on a strided row sample, bit for bit ----
+            sample = np.unique(np.linspace(0, rows - 1, num=min(check_rows, rows)).astype(np.int64))
+            got = out.cpu().numpy()[sample]
+            if kind == "dense":
+                want, want_leaf = oracle.predict(nodes, T, D, data[sample], MISSING, want_leaf=True, threads=min(os.cpu_count() or 1, 16))
+                len_sum, node_bytes, n_nodes = dense_path_len_sum(want_leaf), 4 + info.bits_bytes, T * ta.capi.tree_num_nodes(D)
+            else:
+                want, want_leaf = oracle.sparse_predict(sn, tr, data[sample], MISSING, want_leaf=True, threads=min(os.cpu_count() or 1, 16))
+                len_sum, node_bytes, n_nodes = sparse_path_len_sum(sn, tr, want_leaf), 12, int(sn.size)
+            leg["rows_checked"] = int(sample.size)
+            leg["bitwise_equal_to_cpu_oracle"] = bool(np.array_equal(got.view(np.uint32), want.view(np.uint32)))
+            leg["roofline"] = config_roofline(ms, rows, cols, T, len_sum, node_bytes, n_nodes, cfg)
+            if not leg["bitwise_equal_to_cpu_oracle"]:
+                leg["error"] = f"{cfg}: GPU sums differ from the CPU oracle on the sampled rows"
+            forest.close()
+            del x, out
+        except Exception as err:  # the primary line must survive a failure of a secondary leg
+            leg = {"error": f"{type(err).__name__}: {err}"}
+        leg["leg_seconds"] = round(time.perf_counter() - t_leg, 2)
+        legs[cfg] = leg
+    return legs
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,6 +348,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-host", action="store_true", help="skip the host-resident (PCIe-inclusive) leg")
     ap.add_argument("--no-k4", "--no-tree-leg", dest="no_k4", action="store_true", help="skip the secondary K4 legs")
+    ap.add_argument("--no-configs", action="store_true", help="skip the secondary legs of BASELINE configurations K1, K2, K5")
+    ap.add_argument("--cpu-rows-multi", type=int, default=20_000, help="N > 1: rows of rank 0's shard timed on the CPU oracle")
     ap.add_argument("--k4", action="store_true", help="N > 1: run the secondary K4 legs too (they contain collectives; off by default there)")
     ap.add_argument("--k4-trees", type=int, default=8000)
     ap.add_argument("--k4-chain", action="store_true",
@@ -168,16 +374,24 @@ def main():
     device_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(device_index)
     dist = None
-    if world > 1:
+    # TAHOE_BENCH_FORCE_DIST=1 with one rank: the process group is created anyway (world_size 1 on the real backend) and every
+    # collective of the N > 1 path -- the ones all-reduce, barrier, MAX / MIN all-reduces -- runs through it, so that this
+    # file's torch.distributed surface meets RCCL on a one-GPU box before the driver's 8-GPU run does.
+    force_dist = world == 1 and os.environ.get("TAHOE_BENCH_FORCE_DIST") == "1"
+    use_dist = world > 1 or force_dist
+    if use_dist:
         import datetime
 
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if force_dist:
+            os.environ.setdefault("MASTER_PORT", "29531")
+        kw = {"world_size": 1, "rank": 0} if force_dist else {}
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index), timeout=datetime.timedelta(seconds=300))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index), timeout=datetime.timedelta(seconds=300), **kw)
         else:
-            dist.init_process_group(backend, timeout=datetime.timedelta(seconds=300))
+            dist.init_process_group(backend, timeout=datetime.timedelta(seconds=300), **kw)
 
     class HostHop:
         """torch.distributed through host memory (the gloo rehearsal): same calls, CUDA tensors staged on the CPU."""
@@ -217,7 +431,7 @@ def main():
     # ---- N > 1: the run proves what it ran on -- ranks the process group reports, an all-reduce of ones over them, the
     # device of every rank (n_gpus in the line is this count, not an environment variable) ----
     collective = None
-    if world > 1:
+    if use_dist:
         ranks_seen = int(dist.get_world_size())
         ones = torch.ones(1, dtype=torch.float64, device="cuda")
         all_reduce(ones)
@@ -274,12 +488,12 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
     def max_over_ranks(seconds):
-        if world == 1:
+        if not use_dist:
             return seconds
         t = torch.tensor([seconds], dtype=torch.float64, device="cuda")
         all_reduce(t, op=dist.ReduceOp.MAX)
@@ -288,7 +502,7 @@ def main():
     def agree(ok):
         """Every rank learns whether ALL ranks are fine (one all-reduce of a flag): a failure on one rank makes every rank
         leave the leg together instead of stranding the others in the next collective."""
-        if world == 1:
+        if not use_dist:
             return bool(ok)
         t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device="cuda")
         all_reduce(t, op=dist.ReduceOp.MIN)
@@ -304,7 +518,7 @@ def main():
     fence()
     dt_local = time.perf_counter() - t0
     dt = max_over_ranks(dt_local)
-    if world > 1:  # the spread over the ranks, for the record (value uses the slowest)
+    if use_dist:  # the spread over the ranks, for the record (value uses the slowest)
         t_min = torch.tensor([dt_local], dtype=torch.float64, device="cuda")
         all_reduce(t_min, op=dist.ReduceOp.MIN)
         collective["ms_per_step_fastest_rank"] = round(float(t_min.item()) / args.steps * 1e3, 4)
@@ -323,7 +537,7 @@ def main():
     # and trees this launch processes, divided by the measured kernel time of the WHOLE step (quantise pre-pass + walk).
     # Those bytes are mostly served from LDS (2-byte rank codes, 4-byte nodes), which is the point of the layout, so the
     # figure exceeds the HBM peak: it says how the step compares with the reference's byte model run at HBM speed, not
-    # that HBM moves that much.  What physically binds is under "physical" (PMC counters of profiles/r03) and
+    # that HBM moves that much.  What physically binds is under "physical" (PMC counters of profiles/<round>) and
     # "hbm_frac_measured" (counter bytes over the same time, <= 1).
     strategy_name = ta.STRATEGY_NAMES.get(forest.get_strategy(my_rows), "?")
     b_alg = algorithmic_bytes_per_sample(my_T, D, C, info.bits_bytes) * my_rows
@@ -340,6 +554,12 @@ def main():
     if prof:
         traffic = int(sum((k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024 for n, k in prof["kernels"].items() if "bucket_index" not in n))
         physical = physical_ceilings(prof, walk_ms, quant_ms, my_rows, C)
+    if rank == 0 and have_times and forest.kernel_form(my_rows).startswith("qring_region"):
+        # the fraction <= 1 of this kernel: its node visits per second against the measured ceiling of the LDS-resident walk
+        prop = torch.cuda.get_device_properties(device_index)
+        physical = physical or {"source": None, "note": "no counter profile stamped with these kernel sources"}
+        physical.setdefault("walk", {})["lds_walk_ceiling"] = lds_walk_ceiling(
+            walk_ms, my_rows, my_T, D, prop.multi_processor_count, getattr(prop, "clock_rate", 2_400_000) / 1e6)
     compulsory = my_rows * C * 4 + my_T * n_per_tree * (4 + info.bits_bytes) + my_rows * 4
     roofline = {
         "bound": "hbm", "kernel": f"{strategy_name}: quantise pre-pass + walk" if quant_ms else f"{strategy_name}_kernel",
@@ -352,7 +572,7 @@ def main():
                       "the visits are served from LDS -- see hbm_frac_measured and physical for the ceilings that bind",
         "traffic": traffic,
         "traffic_unit": "HBM-side bytes per step, FETCH_SIZE + WRITE_SIZE of both kernels, raw counters of the rocprofv3 --pmc "
-                        "passes in profiles/r03/pmc_k3.json (null when that profile was not taken with these kernel sources)",
+                        f"passes in profiles/{PROFILE_ROUND}/pmc_k3.json (null when that profile was not taken with these kernel sources)",
         "hbm_frac_measured": round(traffic / (step_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None,
         "kernel_ms_avg": round(step_kernel_ms, 4),
         "kernel_ms_source": "hipEvents on the launch stream, inside the library" if have_times else "wall time of the step",
@@ -363,18 +583,31 @@ def main():
         "compulsory_bytes_per_launch": compulsory,
         "compulsory_frac": round(compulsory / (step_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
         "physical": physical,
+        "frac_le_1": (physical or {}).get("walk", {}).get("lds_walk_ceiling", {}).get("frac"),
+        "frac_le_1_means": "physical.walk.lds_walk_ceiling.frac: the walk kernel against the measured ceiling of its own LDS-resident "
+                           "inner loop (tools/ubench_qwalk.hip); `frac` above is the contract's byte-model figure and exceeds 1",
+        "kernel_form": forest.kernel_form(my_rows),
         "kernel_source_hash": kernel_source_hash(),
     }
 
     # ---- secondary legs: BASELINE config 4 ("K4": 8000 trees).  Which split serves it?  Measured both ways, each with
     # its error against a float64 CPU sum on a row sample.  N = 1: the one-GPU proxies of the 8-GPU run. ----
     k4 = None
-    want_k4 = (not args.no_k4 and (T, D, C, R) == (1000, 12, 256, 1_000_000)) if world == 1 else args.k4
+    want_k4 = args.k4 or (world == 1 and not args.no_k4 and (T, D, C, R) == (1000, 12, 256, 1_000_000))
     if want_k4 and not tree_sharded:
         try:
             k4 = k4_legs(args, ta, sharding, torch, coll, dist, world, rank, fence, max_over_ranks, stream, agree)
         except Exception as err:  # the primary line must survive a failure of a secondary leg
             k4 = {"error": f"{type(err).__name__}: {err}"}
+
+    # ---- secondary legs: BASELINE configurations K1, K2, K5 on this device (N = 1 only, after the primary region) ----
+    configs = None
+    if rank == 0 and world == 1 and not args.no_configs and (T, D, C, R) == (1000, 12, 256, 1_000_000):
+        t_cfg = time.perf_counter()
+        configs = config_legs(ta, torch)
+        configs["K3"] = {"see": "the primary figures of this line", "ms": round(step_kernel_ms, 4), "kernel_form": roofline["kernel_form"]}
+        configs["K4"] = {"see": "k4 in this line (row shards / tree shards on one GPU)"}
+        configs["seconds"] = round(time.perf_counter() - t_cfg, 2)
 
     # ---- host-resident batch (rank 0, N = 1 only): the PCIe-inclusive rate, reported beside `value`, never as it ----
     host_leg = None
@@ -400,33 +633,37 @@ def main():
                 raise SystemExit("bench: host-pipeline predictions differ from the resident-batch predictions")
         pin.close()
 
-    # ---- CPU baseline + parity spot check (rank 0, N = 1 only) ----
+    # ---- CPU baseline + parity spot check (rank 0; N > 1: a shorter leg on the first rows of rank 0's own shard, so that
+    # every line of a scaling run carries its CPU figure from the same run; the other ranks wait at the final barrier) ----
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu:
+    if rank == 0 and not args.no_cpu:
         oracle = _oracle()
-        n_cpu = min(args.cpu_rows, R)
+        n_cpu = min(args.cpu_rows if world == 1 else args.cpu_rows_multi, my_rows)
         tc = time.perf_counter()
         want, _ = oracle.predict(nodes, T, D, data[:n_cpu], MISSING, threads=1)
         cpu_s = time.perf_counter() - tc
         got = preds[:n_cpu].cpu().numpy()
-        exact = bool(np.array_equal(got.view(np.uint32), want.view(np.uint32)))
-        ncores = os.cpu_count() or 1
-        n_all = min(R, n_cpu * min(ncores, 16))
-        tc = time.perf_counter()
-        oracle.predict(nodes, T, D, data[:n_all], MISSING, threads=ncores)
-        cpu_all_s = time.perf_counter() - tc
+        # (tree shards: rank 0's buffer holds the all-reduced sums, which are not the sequential float32 sum -- DESIGN.md 7 -- or,
+        # chained, another rank holds the result: timed, not compared)
+        exact = None if tree_sharded else bool(np.array_equal(got.view(np.uint32), want.view(np.uint32)))
         cpu = {
             "value": round(n_cpu / cpu_s, 1), "unit": "samples/s", "cores": 1, "kind": "port",
-            "sample": f"first {n_cpu} rows of the batch, all {T} trees, single thread (the reference's "
-                      f"predict_on_cpu is single-threaded)",
+            "sample": f"first {n_cpu} rows of " + ("the batch" if world == 1 else f"rank 0's shard (rows {first_row}..)") +
+                      f", all {T} trees, single thread (the reference's predict_on_cpu is single-threaded)",
             "seconds": round(cpu_s, 2),
-            "all_cores": {"value": round(n_all / cpu_all_s, 1), "cores": ncores, "rows": n_all, "seconds": round(cpu_all_s, 2),
-                          "note": "the same scalar port with the rows cut into one block per hardware thread -- every thread "
-                                  "walks the whole 98 MB AoS forest, so this scales far below the core count; a stated baseline "
-                                  "of this port, not what the host could do with a tuned CPU traversal"},
             "gpu_matches_cpu_bitwise_on_sample": exact,
         }
-        if not exact:
+        if world == 1:
+            ncores = os.cpu_count() or 1
+            n_all = min(R, n_cpu * min(ncores, 16))
+            tc = time.perf_counter()
+            oracle.predict(nodes, T, D, data[:n_all], MISSING, threads=ncores)
+            cpu_all_s = time.perf_counter() - tc
+            cpu["all_cores"] = {"value": round(n_all / cpu_all_s, 1), "cores": ncores, "rows": n_all, "seconds": round(cpu_all_s, 2),
+                                "note": "the same scalar port with the rows cut into one block per hardware thread -- every thread "
+                                        "walks the whole 98 MB AoS forest, so this scales far below the core count; a stated baseline "
+                                        "of this port, not what the host could do with a tuned CPU traversal"}
+        if exact is False:
             raise SystemExit("bench: GPU sums differ from the CPU oracle on the sampled rows")
 
     if rank == 0:
@@ -450,9 +687,11 @@ def main():
             "cpu_baseline": cpu,
             "host_pipeline": host_leg,
             "k4": k4,
+            "configs": configs,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
+        dist.barrier()  # rank 0's CPU leg ends here: nobody tears the group down under it
         dist.destroy_process_group()
 
 

@@ -360,6 +360,18 @@ void tahoe_synth_forest(tahoe_dense_node *nodes, int num_trees, int depth, int n
 void tahoe_synth_data(float *out, size_t first_row, size_t rows, int num_cols, uint64_t seed,
                       float missing_prob, float missing, float nan_prob);
 
+/* A second generator, in the style of histogram-trained gradient-boosted models (XGBoost / LightGBM with max_bin <= 255:
+ * the model families the reference is run on, run_all_15_examples.sh:51-65): at most max_bins distinct thresholds per
+ * feature (bin edges = quantiles of a 4096-value sample of the feature), Zipf-skewed feature usage (exponent zipf_s), every
+ * node splits what its ancestors left of the feature's range at a skewed position (unbalanced branches; `weight` = reach
+ * probability), early leaves where hardly any row arrives (+ leaf_prob), features on different scales (scale_decades decades
+ * of spread) and of four shapes (uniform, exponential, bell, small integer counts with half-integer thresholds).
+ * tahoe_synth_data_hist draws rows from the same per-feature distributions (same feature_seed and scale_decades). */
+tahoe_status tahoe_synth_forest_hist(tahoe_dense_node *nodes, int num_trees, int depth, int num_cols, uint64_t seed,
+                                     uint64_t feature_seed, int max_bins, float zipf_s, float leaf_prob, float scale_decades);
+tahoe_status tahoe_synth_data_hist(float *out, size_t first_row, size_t rows, int num_cols, uint64_t seed, uint64_t feature_seed,
+                                   float scale_decades, float missing_prob, float missing);
+
 /* ---- thin device helpers so that host code above this ABI needs no HIP headers ---- */
 tahoe_status tahoe_device_count(int *count);
 tahoe_status tahoe_device_set(int device);

@@ -16,7 +16,9 @@ from .capi import (  # noqa: F401
     save_data_bin,
     save_model_bin,
     synth_data,
+    synth_data_hist,
     synth_forest,
+    synth_forest_hist,
     write_data,
     write_model,
     NODE_DTYPE,

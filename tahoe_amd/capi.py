@@ -152,6 +152,8 @@ _PROTOS = {
     "tahoe_free_host": (None, [_vp]),
     "tahoe_synth_forest": (None, [_vp, _i, _i, _i, C.c_uint64, _f]),
     "tahoe_synth_data": (None, [_vp, _sz, _sz, _i, C.c_uint64, _f, _f, _f]),
+    "tahoe_synth_forest_hist": (_i, [_vp, _i, _i, _i, C.c_uint64, C.c_uint64, _i, _f, _f, _f]),
+    "tahoe_synth_data_hist": (_i, [_vp, _sz, _sz, _i, C.c_uint64, C.c_uint64, _f, _f, _f]),
     "tahoe_device_count": (_i, [C.POINTER(_i)]),
     "tahoe_device_set": (_i, [_i]),
     "tahoe_device_alloc": (_i, [C.POINTER(_vp), _sz, _i]),
@@ -291,6 +293,24 @@ def synth_data(rows: int, num_cols: int, seed: int = 43, missing_prob: float = 0
     data = np.empty((rows, num_cols), dtype=np.float32)
     lib.tahoe_synth_data(data.ctypes.data, first_row, rows, num_cols, seed, missing_prob, missing, nan_prob)
     return data
+
+
+def synth_forest_hist(num_trees: int, depth: int, num_cols: int, seed: int = 42, feature_seed: int = 7, max_bins: int = 255,
+                      zipf_s: float = 1.0, leaf_prob: float = 0.02, scale_decades: float = 3.0) -> np.ndarray:
+    """Forest in the style of histogram-trained GBDT models (tahoe_synth_forest_hist)."""
+    nodes = np.zeros(num_trees * tree_num_nodes(depth), dtype=NODE_DTYPE)
+    _check(lib.tahoe_synth_forest_hist(nodes.ctypes.data, num_trees, depth, num_cols, seed, feature_seed, max_bins, zipf_s, leaf_prob,
+                                       scale_decades), "tahoe_synth_forest_hist")
+    return nodes
+
+
+def synth_data_hist(rows: int, num_cols: int, seed: int = 43, feature_seed: int = 7, scale_decades: float = 3.0,
+                    missing_prob: float = 0.0, missing: float = -999.0, first_row: int = 0) -> np.ndarray:
+    """Rows drawn from the per-feature distributions of synth_forest_hist (same feature_seed / scale_decades)."""
+    out = np.empty((rows, num_cols), dtype=np.float32)
+    _check(lib.tahoe_synth_data_hist(out.ctypes.data, first_row, rows, num_cols, seed, feature_seed, scale_decades, missing_prob,
+                                     missing), "tahoe_synth_data_hist")
+    return out
 
 
 def set_probability_weights(nodes: np.ndarray, num_trees: int, depth: int, lo: float = -1.0, hi: float = 1.0) -> np.ndarray:

@@ -794,6 +794,12 @@ static tahoe_status launch_traversal(tahoe_forest *f, float *sums, uint32_t *lea
     const bool timed = f->profiling && f->prof_count < f->ev_start.size();
     if (timed) TAHOE_HIP_TRY(hipEventRecord(f->ev_start[f->prof_count], stream));
     bool mid_recorded = false;
+    if (timed && !(strategy == TAHOE_STRATEGY_QRING && !f->sp && f->p.num_trees != 0)) {
+        // strategies without a separately timed pre-pass: mid = start, so tahoe_forest_prepass_times reads 0 and
+        // tahoe_forest_kernel_times the whole launch (a sparse handle's quantise pass counts as part of its walk)
+        TAHOE_HIP_TRY(hipEventRecord(f->ev_mid[f->prof_count], stream));
+        mid_recorded = true;
+    }
     const int vec4_ok = (f->p.num_cols % 4 == 0) && ((reinterpret_cast<uintptr_t>(data) & 15u) == 0);
     if (f->p.num_trees == 0) {
         // Nothing to walk: sums are zero (an empty j-loop in predict_on_cpu).
@@ -861,7 +867,6 @@ static tahoe_status launch_traversal(tahoe_forest *f, float *sums, uint32_t *lea
         return fail(TAHOE_ERR_INVALID_ARG, "unknown strategy %d", strategy);
     }
     if (timed) {
-        // strategies without a pre-pass: mid = start (pre-pass time 0)
         if (!mid_recorded) TAHOE_HIP_TRY(hipEventRecord(f->ev_mid[f->prof_count], stream));
         TAHOE_HIP_TRY(hipEventRecord(f->ev_stop[f->prof_count], stream));
         ++f->prof_count;
@@ -1365,7 +1370,7 @@ tahoe_status tahoe_forest_get_info(const tahoe_forest *f, tahoe_forest_info *inf
     info->stream_slots = widef_stream_slots(f);
     info->stream_levels = widef_stream_levels(f);
     info->stream_key_ties = widef_stream_tie_estimate(f);
-    info->qring_tile_rows = info->qring_walkers == 0 ? 0 : qwide_rows(f) ? qwide_rows(f) : qring_regions(f) ? 192 : qring_lds_tile(f) ? 128 : 0;
+    info->qring_tile_rows = info->qring_walkers == 0 ? 0 : qwide_rows(f) ? qwide_rows(f) : qring_code8(f) ? 384 : qring_regions(f) ? 192 : qring_lds_tile(f) ? 128 : 0;
     info->relayout = f->relayout ? 1 : 0;
     info->relayout_swaps = f->relayout_swaps;
     return TAHOE_OK;

@@ -61,8 +61,10 @@ namespace tahoe {
 // batch has fewer tiles than the chip has CUs, every tile is given to `slices` workgroups that each walk a slice of the trees
 // and write the leaf values to leafbuf[tree][row]; ordered_sum_kernel then adds them per row in tree order -- the same
 // sequential float32 sum, where the reference's cub::DeviceSegmentedReduce adds per-block partial sums in another order.
+// CODE8 (region form on u8 codes, qring_internal.h): the tile is K / 2 regions of 128 rows, chain k = half k & 1 of region k >> 1;
+// the loop is the same instruction for instruction except that the feature code is a ds_read_u8.
 template <int NWALK, bool WRITE_LEAF, bool LDSX, bool NARROW = false, bool EXCH = false, int K = 2, bool REG = false, int RING = kQRing,
-          bool SPLIT = false, int BATCH = (RING >= 2 * kQBatch ? kQBatch : RING / 2)>
+          bool SPLIT = false, int BATCH = (RING >= 2 * kQBatch ? kQBatch : RING / 2), bool CODE8 = false>
 __global__ void __launch_bounds__((NWALK + 1) * 64)
     qring_kernel(const uint16_t *__restrict__ xq, const uint32_t *__restrict__ top, const uint4 *__restrict__ blocks,
                  const uint32_t *__restrict__ qinner, const uint32_t *__restrict__ leaf_orig, float *sums,
@@ -77,6 +79,9 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
     static_assert(REG || K == kQRows / 64, "the 128-slot column layout holds exactly two chains");
     static_assert(!REG || (LDSX && NARROW && !EXCH), "regions are a form of the NARROW LDS tile");
     static_assert(BATCH >= 1 && RING >= 2 * BATCH, "ring too small");
+    static_assert(!CODE8 || (REG && K % 2 == 0 && !SPLIT), "u8 codes: whole 128-row regions, no tree slices");
+    constexpr uint32_t MISSC = CODE8 ? kCodeMissing8 : kCodeMissing;
+    constexpr int NREG = CODE8 ? K / 2 : K;  // 32-KiB regions of the tile
     constexpr int TR = 64 * K;             // rows per tile
     constexpr int CS = REG ? 7 : 8;        // log2 of a feature column's bytes
     constexpr int NT = (NWALK + 1) * 64;
@@ -91,7 +96,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
     const int slice = SPLIT ? (int)(blockIdx.x % (unsigned)slices) : 0;
     const int t_begin = SPLIT ? (int)((long long)num_trees * slice / slices) : 0;        // this workgroup's trees
     const int t_end = SPLIT ? (int)((long long)num_trees * (slice + 1) / slices) : num_trees;
-    unsigned char *slots = smem + (REG ? (size_t)K * kRegBytes : LDSX ? (size_t)cols * TR * sizeof(uint16_t) : 0);
+    unsigned char *slots = smem + (REG ? (size_t)NREG * kRegBytes : LDSX ? (size_t)cols * TR * sizeof(uint16_t) : 0);
     const unsigned char *gx = reinterpret_cast<const unsigned char *>(xq + (size_t)tile_id * ((size_t)cols * TR));
     float *ring_vals = reinterpret_cast<float *>(slots + (size_t)NWALK * slot_bytes);
     uint32_t *ring_ready = reinterpret_cast<uint32_t *>(ring_vals + RING * TR);
@@ -105,10 +110,12 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
     }
 
     // ---- stage the quantised tile (already in LDS order): straight 16-byte copies ----
-    if (REG) {  // K consecutive regions of the workspace, each to its 32-KiB-aligned place
+    if (REG) {  // consecutive regions of the workspace (cols x 128 bytes each: 64 rows of u16 or 128 rows of u8 codes), each to
+                // its 32-KiB-aligned place
         const int n16 = cols * kRegRows * 2 / 16;  // 16-byte pieces of a region
-        for (int k = 0; k < K; ++k) {
-            const uint4 *src = reinterpret_cast<const uint4 *>(xq + ((row0 >> 6) + (size_t)k) * ((size_t)cols * kRegRows));
+        const size_t first_region = CODE8 ? row0 >> 7 : row0 >> 6;
+        for (int k = 0; k < NREG; ++k) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(xq + (first_region + (size_t)k) * ((size_t)cols * kRegRows));
             uint4 *dst = reinterpret_cast<uint4 *>(smem + (size_t)k * kRegBytes);
             for (int e = tid; e < n16; e += NT) dst[e] = src[e];
         }
@@ -203,8 +210,9 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
         uint32_t pos[K];  // byte position of this lane's row inside a 256-byte feature column, per chain
     #pragma unroll
         for (int k = 0; k < K; ++k)  // low 32 bits of a generic LDS pointer = the LDS byte address
-            pos[k] = REG ? (uint32_t)(k * kRegBytes) + 2u * (uint32_t)qreg_pos(lane)
-                         : (LDSX ? (uint32_t)reinterpret_cast<uintptr_t>(tile) : 0u) + 2u * (uint32_t)qrow_pos(k * 64 + lane);
+            pos[k] = CODE8 ? (uint32_t)((k >> 1) * kRegBytes) + (uint32_t)qreg8_pos((k & 1) * 64 + lane)
+                     : REG ? (uint32_t)(k * kRegBytes) + 2u * (uint32_t)qreg_pos(lane)
+                           : (LDSX ? (uint32_t)reinterpret_cast<uintptr_t>(tile) : 0u) + 2u * (uint32_t)qrow_pos(k * 64 + lane);
         const size_t n_inner = ((size_t)1 << depth) - 1;
         const uint32_t n_blocks = 1u << (depth - 2);
         const uint32_t first_block_node = n_blocks - 1;
@@ -215,9 +223,9 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
             for (int k = 0; k < K; ++k) {
                 // two dependent steps (the kernel is VALU-bound: this is ~half the instructions of evaluating
                 // both second-level nodes)
-                const bool c0 = q_go_right<MS, NARROW, EXCH>(q_xread<LDSX, NARROW, CS>(gx, na[k].x, pos[k]), na[k].x);
+                const bool c0 = q_go_right<MS, NARROW, EXCH, MISSC>(q_xread<LDSX, NARROW, CS, CODE8>(gx, na[k].x, pos[k]), na[k].x);
                 const uint32_t n1 = c0 ? na[k].z : na[k].y;
-                const bool c1 = q_go_right<MS, NARROW, EXCH>(q_xread<LDSX, NARROW, CS>(gx, n1, pos[k]), n1);
+                const bool c1 = q_go_right<MS, NARROW, EXCH, MISSC>(q_xread<LDSX, NARROW, CS, CODE8>(gx, n1, pos[k]), n1);
                 const uint32_t lo = c0 ? nb[k].z : nb[k].x, hi = c0 ? nb[k].w : nb[k].y;
                 v[k] = __uint_as_float(c1 ? hi : lo);
                 if (WRITE_LEAF) {
@@ -272,10 +280,10 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                     const uint2 pr0 = *reinterpret_cast<const uint2 *>(&slot[2]);
                     uint32_t xc0[K];
     #pragma unroll
-                    for (int k = 0; k < K; ++k) xc0[k] = q_xread<LDSX, NARROW, CS>(gx, node[k], pos[k]);
+                    for (int k = 0; k < K; ++k) xc0[k] = q_xread<LDSX, NARROW, CS, CODE8>(gx, node[k], pos[k]);
     #pragma unroll
                     for (int k = 0; k < K; ++k) {
-                        const uint64_t cm = q_right_mask<MS, NARROW, EXCH>(xc0[k], node[k]);
+                        const uint64_t cm = q_right_mask<MS, NARROW, EXCH, MISSC>(xc0[k], node[k]);
                         i[k] = q_descend(i[k], cm);
                         node[k] = __builtin_amdgcn_inverse_ballot_w64(cm) ? pr0.y : pr0.x;
                     }
@@ -286,20 +294,20 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                     uint2 pr[K];
     #pragma unroll
                     for (int k = 0; k < K; ++k) {
-                        xc[k] = q_xread<LDSX, NARROW, CS>(gx, node[k], pos[k]);
+                        xc[k] = q_xread<LDSX, NARROW, CS, CODE8>(gx, node[k], pos[k]);
                         pr[k] = *reinterpret_cast<const uint2 *>(&slot[2 * i[k]]);  // children 2i, 2i+1
                     }
     #pragma unroll
                     for (int k = 0; k < K; ++k) {
-                        const uint64_t cm = q_right_mask<MS, NARROW, EXCH>(xc[k], node[k]);
+                        const uint64_t cm = q_right_mask<MS, NARROW, EXCH, MISSC>(xc[k], node[k]);
                         i[k] = q_descend(i[k], cm);
                         node[k] = __builtin_amdgcn_inverse_ballot_w64(cm) ? pr[k].y : pr[k].x;
                     }
                 }
     #pragma unroll
                 for (int k = 0; k < K; ++k) {
-                    const uint32_t xc = q_xread<LDSX, NARROW, CS>(gx, node[k], pos[k]);
-                    i[k] = q_descend(i[k], q_right_mask<MS, NARROW, EXCH>(xc, node[k]));
+                    const uint32_t xc = q_xread<LDSX, NARROW, CS, CODE8>(gx, node[k], pos[k]);
+                    i[k] = q_descend(i[k], q_right_mask<MS, NARROW, EXCH, MISSC>(xc, node[k]));
                 }
             }
             uint32_t bsel[K];
@@ -310,8 +318,8 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                     const uint32_t *tree = qinner + (size_t)t * n_inner;
                     for (int l = top_levels; l < depth - 2; ++l) {
                         const uint32_t n = tree[idx];
-                        const uint32_t xc = q_xread<LDSX, NARROW, CS>(gx, n, pos[k]);
-                        idx = 2u * idx + 1u + (q_go_right<MS, NARROW, EXCH>(xc, n) ? 1u : 0u);
+                        const uint32_t xc = q_xread<LDSX, NARROW, CS, CODE8>(gx, n, pos[k]);
+                        idx = 2u * idx + 1u + (q_go_right<MS, NARROW, EXCH, MISSC>(xc, n) ? 1u : 0u);
                     }
                 }
                 bsel[k] = idx - first_block_node;
@@ -692,7 +700,11 @@ static hipError_t q_allow(long long lds)
                           (const void *)&qring_kernel<kReg3Walkers, false, true, true, false, 3, true, kReg3Ring>,
                           (const void *)&qring_kernel<kReg3Walkers, true, true, true, false, 3, true, kReg3Ring>,
                           (const void *)&qring_kernel<15, false, true, true, false, 2, true, kQRing, true>,
-                          (const void *)&qring_kernel<15, true, true, true, false, 2, true, kQRing, true>})
+                          (const void *)&qring_kernel<15, true, true, true, false, 2, true, kQRing, true>,
+                          (const void *)&qring_kernel<kReg8Walkers, false, true, true, false, 6, true, kReg8Ring, false, kReg8Batch, true>,
+                          (const void *)&qring_kernel<kReg8Walkers, true, true, true, false, 6, true, kReg8Ring, false, kReg8Batch, true>,
+                          (const void *)&qring_kernel<15, false, true, true, false, 2, true, kQRing, false, kQBatch, true>,
+                          (const void *)&qring_kernel<15, true, true, true, false, 2, true, kQRing, false, kQBatch, true>})
         if ((e = allow_max_lds(k, (int)lds)) != hipSuccess) return e;
     return hipSuccess;
 }
@@ -725,6 +737,7 @@ static tahoe_status build_group(tahoe_forest *f, const std::vector<InnerNode> &h
         *too_many = max_count;
         return TAHOE_OK;
     }
+    g.max_count = max_count;
     // ---- node codes ----
     auto encode = [&](const InnerNode &n, bool real) -> uint32_t {
         if (!real) return 0u;  // padding below a leaf: both children carry the same value
@@ -824,16 +837,29 @@ tahoe_status qring_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner,
         return TAHOE_OK;
     }
     // ---- cut the forest into tree groups whose features each see <= kQMaxTable distinct thresholds ----
-    // G groups of (nearly) equal size, G as small as the busiest feature allows.  First guess from the node counts per
-    // feature (an upper bound of its distinct thresholds), then G grows until every group fits; trees that differ
-    // wildly in size make that loop longer, never wrong.
+    // G groups of (nearly) equal size, G as small as the busiest feature allows.  First guess from the distinct thresholds
+    // per feature of the whole forest (a group of T / G trees sees at most that many, usually ~1 / G of them), then G grows
+    // until every group fits; trees that differ wildly in size make that loop longer, never wrong.
     size_t G = 1;
     {
-        std::vector<size_t> per_feature((size_t)cols, 0);
+        // distinct thresholds per feature over the whole forest (sort + unique per feature, features in parallel): a forest of
+        // histogram-trained trees has hundreds of thousands of nodes on its busiest feature and a few hundred distinct
+        // thresholds -- counting nodes (round 1-3) cut such forests into several groups for nothing, each with its own
+        // quantise pass and walk launches (KR3: 4 groups, 5.9 ms instead of one group)
+        std::vector<std::vector<float>> all((size_t)cols);
         for (size_t i = 0; i < T * f->n_inner; ++i)
-            if (h_real[i] && !std::isnan(h_inner[i].thr)) ++per_feature[h_inner[i].meta & kMetaFidMask];
-        const size_t most = *std::max_element(per_feature.begin(), per_feature.end());
-        if (most > (size_t)kQMaxTable + kQMaxTable / 2) G = (most + kQMaxTable - 1) / kQMaxTable;  // below 1.5x: try one group first
+            if (h_real[i] && !std::isnan(h_inner[i].thr)) all[h_inner[i].meta & kMetaFidMask].push_back(h_inner[i].thr);
+        std::vector<size_t> distinct((size_t)cols, 0);
+        parallel_for((size_t)cols, 4, [&](size_t c_lo, size_t c_hi) {
+            for (size_t c = c_lo; c < c_hi; ++c) {
+                auto &v = all[c];
+                std::sort(v.begin(), v.end());
+                distinct[c] = (size_t)(std::unique(v.begin(), v.end()) - v.begin());
+                std::vector<float>().swap(v);
+            }
+        });
+        const size_t most = *std::max_element(distinct.begin(), distinct.end());
+        if (most > (size_t)kQMaxTable) G = (most + kQMaxTable - 1) / kQMaxTable;  // a group sees at most the forest's distinct count
         if (const char *k = getenv("TAHOE_QRING_GROUPS"))  // experiments: at least this many groups (K4: 8 groups of 1000 trees
             G = std::max(G, (size_t)std::max(atoi(k), 1));  // take the bucketed quantise kernel, 4 of 2000 the two-pass one)
     }
@@ -867,6 +893,13 @@ tahoe_status qring_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner,
             return TAHOE_OK;
         }
         G = std::max(G + 1, (size_t)((double)G * worst / kQMaxTable + 0.999));
+    }
+    // u8 codes (histogram-trained forests: <= 254 thresholds per feature in every group): region form only
+    {
+        int most = 0;
+        for (const tahoe_qgroup &g : q->groups) most = std::max(most, g.max_count);
+        const char *e8 = getenv("TAHOE_QRING_CODE8");  // experiments: 0 keeps u16 codes
+        q->code8 = q->reg && most <= kQMaxTable8 && qreg_lds_for(6, kReg8Walkers, kReg8Ring, true) <= f->lds_limit && !(e8 && atoi(e8) == 0);
     }
     // kernels that need more than 64 KiB of dynamic LDS
     hipError_t e;
@@ -903,6 +936,7 @@ void qring_destroy(tahoe_forest *f)
 
 int qring_groups(const tahoe_forest *f) { return f->q ? (int)f->q->groups.size() : 0; }
 bool qring_regions(const tahoe_forest *f) { return f->q && f->q->reg; }
+bool qring_code8(const tahoe_forest *f) { return f->q && f->q->code8; }
 
 // The quantised copy of the batch lives in a grow-only workspace owned by the handle.
 static int q_slices(const tahoe_forest *f, size_t rows, int *most_out);
@@ -987,7 +1021,7 @@ static tahoe_status qring_reserve_leafbuf(tahoe_forest *f, size_t rows, int tree
 }
 
 template <int NWALK, bool LDSX = true, bool NARROW = false, bool EXCH = false, int K = 2, bool REG = false, int RING = kQRing,
-          bool SPLIT = false>
+          bool SPLIT = false, int BATCH = (RING >= 2 * kQBatch ? kQBatch : RING / 2), bool CODE8 = false>
 static void q_launch(tahoe_forest *f, const tahoe_qgroup &g, float *sums, const float *sums_in, uint32_t *leaf_out,
                      size_t rows, hipStream_t stream, int cshift, int slices = 1, size_t row_begin = 0)
 {
@@ -996,15 +1030,15 @@ static void q_launch(tahoe_forest *f, const tahoe_qgroup &g, float *sums, const 
     if (grid == 0) return;
     float *leafbuf = SPLIT ? q->leafbuf : nullptr;
     const size_t leaf_stride = SPLIT ? q->leaf_stride : 0;
-    const int lds = REG ? (int)qreg_lds_for(K, NWALK, RING) : (int)qring_lds_for(f, NWALK, LDSX);
+    const int lds = REG ? (int)qreg_lds_for(K, NWALK, RING, CODE8) : (int)qring_lds_for(f, NWALK, LDSX);
     const uint32_t *leaf_orig = f->leaf_orig + (size_t)g.tree_lo * f->n_leaf;
     if (leaf_out)
-        hipLaunchKernelGGL((qring_kernel<NWALK, true, LDSX, NARROW, EXCH, K, REG, RING, SPLIT>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, g.top,
+        hipLaunchKernelGGL((qring_kernel<NWALK, true, LDSX, NARROW, EXCH, K, REG, RING, SPLIT, BATCH, CODE8>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, g.top,
                            g.blocks, g.qinner, leaf_orig, sums, leaf_out, rows, f->p.num_cols, g.num_trees, f->depth,
                            q->top_levels, q->top_stride, q->chunk_flags, f->error_flag, sums_in, g.tree_lo, f->p.num_trees, cshift, leafbuf, leaf_stride,
                            slices, row_begin);
     else
-        hipLaunchKernelGGL((qring_kernel<NWALK, false, LDSX, NARROW, EXCH, K, REG, RING, SPLIT>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, g.top,
+        hipLaunchKernelGGL((qring_kernel<NWALK, false, LDSX, NARROW, EXCH, K, REG, RING, SPLIT, BATCH, CODE8>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, g.top,
                            g.blocks, g.qinner, leaf_orig, sums, leaf_out, rows, f->p.num_cols, g.num_trees, f->depth,
                            q->top_levels, q->top_stride, q->chunk_flags, f->error_flag, sums_in, g.tree_lo, f->p.num_trees, cshift, leafbuf, leaf_stride,
                            slices, row_begin);
@@ -1057,9 +1091,13 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
     const int trs = q->reg ? 6 : wide == 64 ? 6 : wide == 32 ? 5 : wide == 16 ? 4 : 7;
     size_t rows3 = 0;   // rows [0, rows3) in 192-row tiles, a multiple of 384
     int chains = 2;     // form of the remaining rows [rows3, rows)
-    if (q->reg) qreg_plan(rows, f->num_cus, f->knob_qring_chains, &rows3, &chains);  // TAHOE_QRING_CHAINS = 2 / 3 forces one form
     int most = 1;
     const int slices = q_slices(f, rows, &most);  // small batches of the region form: tree slices per tile (SPLIT)
+    const bool code8 = q->code8 && slices <= 1;   // u8 codes: 384-row tiles for whole waves, 128-row tiles for the remainder
+    if (code8)
+        qreg_plan(rows, f->num_cus, f->knob_qring_chains, &rows3, &chains, kReg8Cost, 384);
+    else if (q->reg)
+        qreg_plan(rows, f->num_cus, f->knob_qring_chains, &rows3, &chains);  // TAHOE_QRING_CHAINS = 2 / 3 forces one form
     if (slices > 1) {
         const tahoe_status ls = qring_reserve_leafbuf(f, rows, most);  // no-op after tahoe_forest_reserve / a first predict
         if (ls != TAHOE_OK) return ls;
@@ -1071,7 +1109,7 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
         TAHOE_HIP_TRY(hipMemsetAsync(q->chunk_flags, 0, q->n_chunk_flags * sizeof(uint32_t), stream));
         int cshift = 0;  // rows per quantise workgroup = rows per "missing seen" flag, as a shift
         {
-            const tahoe_status qs = quantize_launch(f, g, data, rows, trs, q->reg ? 1 : 0, stream, &cshift);
+            const tahoe_status qs = quantize_launch(f, g, data, rows, trs, code8 ? 2 : q->reg ? 1 : 0, stream, &cshift);
             if (qs != TAHOE_OK) return qs;
         }
         TAHOE_HIP_TRY(hipGetLastError());
@@ -1090,6 +1128,15 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
             case 15:
                 if (q->reg && slices > 1)
                     q_launch<15, true, true, false, 2, true, kQRing, true>(f, g, sums, sums_in, leaf_out, rows, stream, cshift, slices);
+                else if (code8) {
+                    if (rows3 > 0)
+                        q_launch<kReg8Walkers, true, true, false, 6, true, kReg8Ring, false, kReg8Batch, true>(f, g, sums, sums_in, leaf_out, rows3, stream, cshift);
+                    if (chains == 3)
+                        q_launch<kReg8Walkers, true, true, false, 6, true, kReg8Ring, false, kReg8Batch, true>(f, g, sums, sums_in, leaf_out, rows, stream, cshift, 1,
+                                                                                                         rows3);
+                    else
+                        q_launch<15, true, true, false, 2, true, kQRing, false, kQBatch, true>(f, g, sums, sums_in, leaf_out, rows, stream, cshift, 1, rows3);
+                }
                 else if (q->reg) {
                     if (rows3 > 0)
                         q_launch<kReg3Walkers, true, true, false, 3, true, kReg3Ring>(f, g, sums, sums_in, leaf_out, rows3, stream, cshift);
@@ -1128,6 +1175,7 @@ int qring_form(const tahoe_forest *f, size_t rows)
     if (q_slices(f, rows, &most) > 1) return TAHOE_FORM_QRING_SPLIT;
     size_t rows3 = 0;
     int chains = 2;
+    if (q->code8) return TAHOE_FORM_QRING_REGION8;
     qreg_plan(rows, f->num_cus, f->knob_qring_chains, &rows3, &chains);
     if (rows3 > 0 && chains == 2) return TAHOE_FORM_QRING_REGION_MIXED;
     return chains == 3 ? TAHOE_FORM_QRING_REGION3 : TAHOE_FORM_QRING_REGION2;

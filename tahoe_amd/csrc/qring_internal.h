@@ -20,6 +20,7 @@
 struct tahoe_qgroup {
     int tree_lo = 0, num_trees = 0;
     int max_table = 0;            // floats of the largest per-feature search tree (2^p)
+    int max_count = 0;            // distinct thresholds of the busiest feature (codes run 0 .. max_count)
     int pair_lds_floats = 0;      // LDS floats of quantize_pair_kernel; 0 = odd num_cols, single-feature form
     int multi_q = 0;              // quantize_multi_kernel<Q>: 4 or 2 (16 / 8 features per workgroup); 0 = tables too large
     float *tables = nullptr;      // concatenated search trees
@@ -43,6 +44,8 @@ struct tahoe_qstate {
     bool narrow = false;          // node words in the NARROW layout (num_cols <= 256, 15 walkers, LDS tile)
     bool reg = false;             // ... in its region form: fid << 7, tiles of two or three 64-row regions (qring.hip)
     bool sparse = false;          // the handle is a sparse forest: tables, workspace and region tiles only (sparse.hip walks)
+    bool code8 = false;           // region form with every table <= 254 entries: large batches are quantised to u8 codes and walked
+                                  // in 384-row tiles (six chains per lane)
     int wide_rt = 0;              // rows per tile of the wide-row form (qwide_kernel), fixed at create; 0 = not used
     int wide_lw = 0;              // ... and the top levels its LDS slots hold
     int wide_kg = 1;              // ... and the groups of trees a walker wave holds (chains per lane): 1 or 3
@@ -80,10 +83,26 @@ constexpr int kReg3Walkers = 14;
 constexpr int kReg3Ring = 10;
 constexpr int kQMaxTable = 32767;
 // LDS of the region form: K regions of 32 KiB, walker slots, ring
-inline long long qreg_lds_for(int k, int nwalk, int ring)
+inline long long qreg_lds_for(int k, int nwalk, int ring, bool code8 = false)
 {
-    return (long long)k * kRegBytes + (long long)nwalk * kQSlotBytes + (long long)ring * k * kRegRows * 4 + (ring + 1) * 4LL;
+    return (long long)(code8 ? k / 2 : k) * kRegBytes + (long long)nwalk * kQSlotBytes + (long long)ring * k * kRegRows * 4 + (ring + 1) * 4LL;
 }
+// u8 form: six chains (384-row tiles of three 128-row regions) for whole waves of workgroups, two chains (one region) for
+// the remainder; walkers / ring / consumer batch of the 384-row tile (96 KiB + 13 x 4 KiB + 7 x 1.5 KiB = 162,336 B)
+#ifndef TAHOE_Q8_WALKERS
+#define TAHOE_Q8_WALKERS 13
+#endif
+#ifndef TAHOE_Q8_RING
+#define TAHOE_Q8_RING 7
+#endif
+#ifndef TAHOE_Q8_BATCH
+#define TAHOE_Q8_BATCH 3
+#endif
+constexpr int kReg8Walkers = TAHOE_Q8_WALKERS, kReg8Ring = TAHOE_Q8_RING, kReg8Batch = TAHOE_Q8_BATCH;
+#ifndef TAHOE_Q8_COST
+#define TAHOE_Q8_COST 205  // time of a 384-row u8 tile in percent of a 128-row u8 tile (first estimate from T(K) = 1.9 + 1.06 K)
+#endif
+constexpr size_t kReg8Cost = TAHOE_Q8_COST;
 // Region form: 192-row tiles (three chains, 14 walkers) take 1.33 x the time of 128-row tiles (two chains, 15 walkers),
 // i.e. 0.89 per row -- but a last, partly filled wave of workgroups costs a whole tile time.  A batch is therefore
 // walked as n whole waves of 192-row tiles followed by a remainder in whichever form is cheaper, n chosen to minimise
@@ -91,8 +110,10 @@ inline long long qreg_lds_for(int k, int nwalk, int ring)
 // 10 k rows: 79 tiles of 128).  Any cut is correct.  *rows3 = rows [0, rows3) in 192-row tiles (a multiple of 384),
 // *chains = form of the remaining rows [rows3, rows).  `force` = 2 / 3: one form for the whole batch.  cost3 = time of a
 // 192-row tile in percent of a 128-row tile (dense walk: 133; the sparse walk's three chains cost more: 161, sparse.hip).
-inline void qreg_plan(size_t rows, int num_cus, int force, size_t *rows3, int *chains, size_t cost3 = 133)
+inline void qreg_plan(size_t rows, int num_cus, int force, size_t *rows3, int *chains, size_t cost3 = 133, size_t big = 192)
 {
+    // (`big` = rows of the large tile: 192 for u16 codes; the u8 form plans 384-row tiles against 128-row ones with its own
+    // cost ratio and reads *chains == 3 as "the large tile")
     *rows3 = 0;
     *chains = 2;
     const size_t cus = (size_t)std::max(num_cus, 1);
@@ -102,13 +123,13 @@ inline void qreg_plan(size_t rows, int num_cus, int force, size_t *rows3, int *c
         return;
     }
     size_t best = SIZE_MAX;
-    for (size_t n = 0; n <= waves(rows, 192); ++n) {
-        const size_t r3 = std::min(rows, n * cus * 192 / 384 * 384), rem = rows - r3;
-        const size_t c2 = 100 * waves(rem, 128), c3 = cost3 * waves(rem, 192);
-        const size_t cost = cost3 * waves(r3, 192) + std::min(c2, c3);
+    for (size_t n = 0; n <= waves(rows, big); ++n) {
+        const size_t r3 = std::min(rows, n * cus * big / 384 * 384), rem = rows - r3;
+        const size_t c2 = 100 * waves(rem, 128), c3 = cost3 * waves(rem, big);
+        const size_t cost = cost3 * waves(r3, big) + std::min(c2, c3);
         if (cost < best) {
             best = cost;
-            *rows3 = rem ? r3 : 0;               // a pure 192-row plan is "no first part, remainder in form 3"
+            *rows3 = rem ? r3 : 0;               // a pure large-tile plan is "no first part, remainder in form 3"
             *chains = rem ? (c2 <= c3 ? 2 : 3) : 3;
         }
     }
@@ -137,6 +158,30 @@ __device__ __forceinline__ size_t q_tile_index(size_t r, int f, int cols, int tr
     return (((r >> trs) * (size_t)cols + (size_t)f) << trs) + (size_t)(trs == 7 ? qrow_pos(rr) : perm ? qreg_pos(rr) : rr);
 }
 
+// ---- 8-bit codes (forests whose features each see <= 254 distinct thresholds within a tree group: histogram-trained models) ----
+// A region of the same 32 KiB then holds 128 rows: column = 128 bytes, one byte per row; row r (0..127) sits at byte
+// 4 * (r & 31) + 2 * (r >> 6) + ((r >> 5) & 1), i.e. dword d of a column holds rows d, d + 32 (first 64-row half) and d + 64, d + 96
+// (second half): the 32 lanes of a half-wave that walk one half read 32 different dwords = 32 banks for any per-lane fid, as with
+// u16 codes.  A walk tile is K / 2 consecutive regions, chain k of a lane = half k & 1 of region k >> 1 (row 64 k + lane of the
+// tile): six chains = 384 rows per staged top where u16 codes hold 192.  The missing code is 0xFF.
+constexpr int kReg8Rows = 128;
+constexpr uint32_t kCodeMissing8 = 0xFFu;
+constexpr int kQMaxTable8 = 254;  // codes 0 .. 254, 255 = missing
+__host__ __device__ __forceinline__ int qreg8_pos(int r) { return ((r & 31) << 2) | ((r >> 6) << 1) | ((r >> 5) & 1); }
+__device__ __forceinline__ size_t q_tile_index8(size_t r, int f, int cols)
+{
+    return (((r >> 7) * (size_t)cols + (size_t)f) << 7) + (size_t)qreg8_pos((int)(r & 127));
+}
+// Stores the code of (row r, feature f) in the layout `perm` selects: 0 = tiles of 2^trs rows in order, 1 = 64-row regions of
+// u16 codes (qreg_pos), 2 = 128-row regions of u8 codes (the workspace is then a byte array; `missing` codes become 0xFF).
+__device__ __forceinline__ void q_store_code(uint16_t *xq, size_t r, int f, int cols, int trs, int perm, uint32_t code)
+{
+    if (perm == 2)
+        reinterpret_cast<uint8_t *>(xq)[q_tile_index8(r, f, cols)] = (uint8_t)(code == kCodeMissing ? kCodeMissing8 : code);
+    else
+        xq[q_tile_index(r, f, cols, trs, perm)] = (uint16_t)code;
+}
+
 constexpr int kQuantPairThreads = 1024;
 
 template <typename T>
@@ -160,14 +205,14 @@ inline hipError_t q_upload(T **dst, const T *src, size_t count, size_t *total)
 // (fid * 256) is a bit field of the node word and one v_bfi forms the read address (q_xread).
 // EX (NARROW only; probability-guided re-layout): bit 7 of the node word marks a node whose children are stored swapped;
 // the condition is inverted there.  One more v_cmp (the sign of byte 0) and one s_xor per step.
-template <bool MS, bool NARROW, bool EX = false>
+template <bool MS, bool NARROW, bool EX = false, uint32_t MISSC = kCodeMissing>
 __device__ __forceinline__ uint64_t q_right_mask(uint32_t xc, uint32_t node)
 {
     static_assert(!EX || NARROW, "the exchange bit lives in the NARROW node word");
     const uint64_t ge = __builtin_amdgcn_uicmp(xc, NARROW ? node >> 16 : node & 0xFFFFu, 35 /* ICMP_UGE */);
     uint64_t right = ge;
     if (MS) {
-        const uint64_t ms = __builtin_amdgcn_uicmp(xc, kCodeMissing, 32 /* ICMP_EQ */);
+        const uint64_t ms = __builtin_amdgcn_uicmp(xc, MISSC, 32 /* ICMP_EQ: the row's code says "missing" (0xFFFF; 0xFF for u8 codes) */);
         const uint64_t ndl = NARROW ? __builtin_amdgcn_uicmp(node & 0x1u, 0u, 32 /* ICMP_EQ: def_left clear */)
                                     : __builtin_amdgcn_sicmp((int)node, -1, 38 /* ICMP_SGT: bit 31 (def_left) clear */);
         right = (ge & ~ms) | (ms & ndl);
@@ -175,10 +220,10 @@ __device__ __forceinline__ uint64_t q_right_mask(uint32_t xc, uint32_t node)
     if (EX) right ^= __builtin_amdgcn_sicmp((int)(int8_t)(node & 0xFFu), 0, 40 /* ICMP_SLT: bit 7 (exchange) set */);
     return right;
 }
-template <bool MS, bool NARROW, bool EX = false>
+template <bool MS, bool NARROW, bool EX = false, uint32_t MISSC = kCodeMissing>
 __device__ __forceinline__ bool q_go_right(uint32_t xc, uint32_t node)
 {
-    return __builtin_amdgcn_inverse_ballot_w64(q_right_mask<MS, NARROW, EX>(xc, node));
+    return __builtin_amdgcn_inverse_ballot_w64(q_right_mask<MS, NARROW, EX, MISSC>(xc, node));
 }
 // i <- 2i + (lane's bit of mask): one v_addc with the mask as carry-in
 __device__ __forceinline__ uint32_t q_descend(uint32_t i, uint64_t right_mask)
@@ -196,15 +241,18 @@ __device__ __forceinline__ uint32_t q_descend(uint32_t i, uint64_t right_mask)
 // the quantised tile in global memory (L2-resident: one 128-row tile of 3072 columns is 768 KiB); `gx` = the
 // tile's base, posb = byte position inside a column.
 typedef const uint16_t __attribute__((address_space(3))) *lds_u16_ptr;
-template <bool LDSX, bool NARROW, int CSHIFT = 8>
+typedef const uint8_t __attribute__((address_space(3))) *lds_u8_ptr;
+template <bool LDSX, bool NARROW, int CSHIFT = 8, bool U8 = false>
 __device__ __forceinline__ uint32_t q_xread(const unsigned char *gx, uint32_t node, uint32_t posb)
 {
     static_assert(!NARROW || CSHIFT == 8 || CSHIFT == 7, "the NARROW layouts have 256- or 128-byte feature columns");
+    static_assert(!U8 || (LDSX && NARROW && CSHIFT == 7), "u8 codes are a form of the region layout");
     if (LDSX && NARROW) {
         // The tile starts at LDS address 0 (checked at kernel entry).  CSHIFT = 8: posb < 256, address = node[15:8] : posb[7:0].
         // CSHIFT = 7 (64-row regions at multiples of 32 KiB): posb = region base + slot (< 128), address takes node[14:7].
         uint32_t addr;
         asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(addr) : "s"(0xFFu << (CSHIFT == 7 ? 7 : 8)), "v"(node), "v"(posb));
+        if (U8) return *reinterpret_cast<lds_u8_ptr>(addr);  // 128-row regions of u8 codes: ds_read_u8
         return *reinterpret_cast<lds_u16_ptr>(addr);
     }
     if (LDSX) {

@@ -90,8 +90,7 @@ __global__ void __launch_bounds__(kQuantThreads) quantize_kernel(const float *__
                     const bool ms = fabsf(x[u] - missing) <= kMissingEps;
                     saw_missing |= ms;
                     const uint32_t code = ms ? kCodeMissing : (uint32_t)(cnt[u] - size[j]);
-                    xq[q_tile_index(r, f0 + j, cols, trs, perm)] =
-                        (uint16_t)code;
+                    q_store_code(xq, r, f0 + j, cols, trs, perm, code);
                 }
             }
         }
@@ -168,16 +167,15 @@ __global__ void __launch_bounds__(kQuantPairThreads)
             for (int u = 0; u < U; ++u) {
                 const size_t r = rb + (size_t)u * blockDim.x;
                 if (r < r1) {
-                    uint16_t *dst = xq + q_tile_index(r, f0, cols, trs, perm);
                     if (do0) {
                         const bool ms = fabsf(xv[u].x - missing) <= kMissingEps;
                         saw_missing |= ms;
-                        dst[0] = (uint16_t)(ms ? kCodeMissing : (uint32_t)(c0[u] - size0));
+                        q_store_code(xq, r, f0, cols, trs, perm, ms ? kCodeMissing : (uint32_t)(c0[u] - size0));
                     }
                     if (do1) {
                         const bool ms = fabsf(xv[u].y - missing) <= kMissingEps;
                         saw_missing |= ms;
-                        dst[(size_t)1 << trs] = (uint16_t)(ms ? kCodeMissing : (uint32_t)(c1[u] - size1));
+                        q_store_code(xq, r, f0 + 1, cols, trs, perm, ms ? kCodeMissing : (uint32_t)(c1[u] - size1));
                     }
                 }
             }
@@ -301,11 +299,10 @@ __global__ void __launch_bounds__(kQuantPairThreads)
         for (int u = 0; u < U; ++u) {
             const size_t r = rb + (size_t)u * blockDim.x;
             if (r < r1) {
-                uint16_t *dst = xq + q_tile_index(r, f0, cols, trs, perm);
                 const bool ms0 = fabsf(xv[u].x - missing) <= kMissingEps, ms1 = fabsf(xv[u].y - missing) <= kMissingEps;
                 saw_missing |= ms0 | ms1;
-                dst[0] = (uint16_t)(ms0 ? kCodeMissing : (uint32_t)c0[u]);
-                dst[(size_t)1 << trs] = (uint16_t)(ms1 ? kCodeMissing : (uint32_t)c1[u]);
+                q_store_code(xq, r, f0, cols, trs, perm, ms0 ? kCodeMissing : (uint32_t)c0[u]);
+                q_store_code(xq, r, f0 + 1, cols, trs, perm, ms1 ? kCodeMissing : (uint32_t)c1[u]);
             }
         }
     }
@@ -382,7 +379,7 @@ __global__ void __launch_bounds__(kQuantPairThreads)
                 if (r < r1) {
                     const bool ms = fabsf(x[u] - missing) <= kMissingEps;
                     saw_missing |= ms;
-                    xq[q_tile_index(r, fq + j, cols, trs, perm)] = (uint16_t)(ms ? kCodeMissing : (uint32_t)(cnt[u] - size[j]));
+                    q_store_code(xq, r, fq + j, cols, trs, perm, ms ? kCodeMissing : (uint32_t)(cnt[u] - size[j]));
                 }
             }
         }

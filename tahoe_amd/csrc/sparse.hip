@@ -723,14 +723,24 @@ static tahoe_status sparse_q_build(tahoe_forest *f, const std::vector<uint2> &cn
         memcpy(&v, &c.x, 4);
         return v;
     };
-    // tree groups: G as small as the busiest feature allows (first guess from node counts, then grow until every group fits)
+    // tree groups: G as small as the busiest feature allows (first guess from the DISTINCT thresholds per feature of the whole
+    // forest -- node counts would cut a forest of histogram-trained trees into groups for nothing --, then grow until every group fits)
     size_t G = 1;
     {
-        std::vector<size_t> per_feature((size_t)cols, 0);
+        std::vector<std::vector<float>> all((size_t)cols);
         for (const uint2 &c : cn)
-            if (is_inner(c) && !std::isnan(thr_of(c))) ++per_feature[c.y & 0x7fffu];
-        const size_t most = *std::max_element(per_feature.begin(), per_feature.end());
-        if (most > (size_t)kQMaxTable + kQMaxTable / 2) G = (most + kQMaxTable - 1) / kQMaxTable;
+            if (is_inner(c) && !std::isnan(thr_of(c))) all[c.y & 0x7fffu].push_back(thr_of(c));
+        std::vector<size_t> distinct((size_t)cols, 0);
+        parallel_for((size_t)cols, 4, [&](size_t c_lo, size_t c_hi) {
+            for (size_t c = c_lo; c < c_hi; ++c) {
+                auto &v = all[c];
+                std::sort(v.begin(), v.end());
+                distinct[c] = (size_t)(std::unique(v.begin(), v.end()) - v.begin());
+                std::vector<float>().swap(v);
+            }
+        });
+        const size_t most = *std::max_element(distinct.begin(), distinct.end());
+        if (most > (size_t)kQMaxTable) G = (most + kQMaxTable - 1) / kQMaxTable;
     }
     std::vector<uint2> qn(cn.size());
     const size_t bytes_before = f->device_bytes;

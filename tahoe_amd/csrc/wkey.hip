@@ -80,6 +80,39 @@ constexpr float kWkTieLimit = 1.0e-4f;
 #ifndef TAHOE_WS_ABLATE
 #define TAHOE_WS_ABLATE 0
 #endif
+// Non-temporal hints on the two read-once / write-once streams that share L2 with the bottom blocks (make WKNT=bits; an
+// experiment knob, profiles/r04/experiments.json): bit 0 = the loaders' row loads, bit 1 = the walkers' leaf-value stores and
+// the summer wave's loads of them.  Results are unchanged (only the cache policy of the instructions differs).
+#ifndef TAHOE_WK_NT
+#define TAHOE_WK_NT 1  // measured on K2 (profiles/r04/k2_nt.txt): row loads nt 0.597 -> 0.574 ms; leaf stores + summer loads nt 0.684 (worse)
+#endif
+typedef float __attribute__((ext_vector_type(4))) wk_f4;  // (HIP's float4 is a struct: __builtin_nontemporal_load wants a native vector)
+__device__ __forceinline__ float4 wk_load_row16(const unsigned char *p)
+{
+#if TAHOE_WK_NT & 1
+    const wk_f4 v = __builtin_nontemporal_load(reinterpret_cast<const wk_f4 *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *reinterpret_cast<const float4 *>(p);
+#endif
+}
+__device__ __forceinline__ float4 wk_load_leaf16(const float *p)
+{
+#if TAHOE_WK_NT & 2
+    const wk_f4 v = __builtin_nontemporal_load(reinterpret_cast<const wk_f4 *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *reinterpret_cast<const float4 *>(p);
+#endif
+}
+__device__ __forceinline__ void wk_store_leaf(float *p, float v)
+{
+#if TAHOE_WK_NT & 2
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
 #define WK_NO_GATHER (TAHOE_WS_ABLATE == 1)
 #define WK_NO_WALK (TAHOE_WS_ABLATE == 2 || TAHOE_WS_ABLATE == 5)
 #define WK_NO_LOAD (TAHOE_WS_ABLATE == 3 || TAHOE_WS_ABLATE == 6)
@@ -176,7 +209,7 @@ __global__ void __launch_bounds__((kWkLoaders + 1 + kWkWalkers) * 64)
                 const int off = min((c * 4 + u) * 1024 + lane * 16, row_bytes - 16);
                 r[u] = make_float4(0.f, 0.f, 0.f, 0.f);
 #if !WK_NO_LOAD
-                r[u] = *reinterpret_cast<const float4 *>(src + off);
+                r[u] = wk_load_row16(src + off);
 #endif
             }
         };
@@ -284,7 +317,7 @@ __global__ void __launch_bounds__((kWkLoaders + 1 + kWkWalkers) * 64)
                 int t = 0;
 #if !WK_NO_ADD
                 for (; t + 8 <= num_trees; t += 8) {
-                    const float4 p = *reinterpret_cast<const float4 *>(v + t), q = *reinterpret_cast<const float4 *>(v + t + 4);
+                    const float4 p = wk_load_leaf16(v + t), q = wk_load_leaf16(v + t + 4);
                     sum += p.x;
                     sum += p.y;
                     sum += p.z;
@@ -449,7 +482,7 @@ __global__ void __launch_bounds__((kWkLoaders + 1 + kWkWalkers) * 64)
         if constexpr (KC > GS) bottom(std::integral_constant<int, GS>{});
 #pragma unroll
         for (int j = 0; j < KC; ++j) {
-            if (leafbuf && t[j] < num_trees) leafbuf[(r0 + k) * (size_t)tv + t[j]] = leaf[j];
+            if (leafbuf && t[j] < num_trees) wk_store_leaf(&leafbuf[(r0 + k) * (size_t)tv + t[j]], leaf[j]);
             if (WRITE_LEAF) {
                 if (t[j] < num_trees)
                     leaf_out[(r0 + k) * (size_t)num_trees + t[j]] =

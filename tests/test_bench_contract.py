@@ -1,22 +1,26 @@
 """The bench.py output contract, checked on the line recorded from the last default run on the GPU box
-(profiles/r02/bench_default_line.json).  CPU test: guards the keys the driver and the judge read."""
+(profiles/r04/bench_default_line.json).  CPU test: guards the keys the driver and the judge read."""
 import json
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def recorded_line():
+    return json.load(open(os.path.join(ROOT, "profiles", "r04", "bench_default_line.json")))
+
+
 def test_recorded_bench_line_has_the_contract_keys():
-    line = json.load(open(os.path.join(ROOT, "profiles", "r02", "bench_default_line.json")))
+    line = recorded_line()
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "configs"):
         assert key in line, key
-    assert line["unit"] == "samples/s" and line["higher_is_better"] is True and line["scaling"] == "weak"
+    assert line["unit"] == "samples/s" and line["higher_is_better"] is True and line["scaling"] == "strong"
     assert line["vs_baseline"] is None and line["data"] == "synthetic" and line["dtype"] == "f32"
     assert "workload" in line["config"] and "model" not in line["config"]
     assert abs(line["value"] - line["config"]["rows_per_step"] / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-3
     r = line["roofline"]
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_le_1", "kernel_form"):
         assert key in r, key
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
@@ -35,6 +39,39 @@ def test_recorded_bench_line_has_the_contract_keys():
     assert c["kind"] == "port" and c["cores"] == 1 and c["gpu_matches_cpu_bitwise_on_sample"] is True
 
 
+def test_recorded_line_carries_a_fraction_below_one():
+    """next to the byte-model figure (> 1) the line has the one honest fraction this kernel has -- its node
+    visits per second against the measured ceiling of its own LDS-resident inner loop (tools/ubench_qwalk.hip)."""
+    r = recorded_line()["roofline"]
+    c = r["physical"]["walk"]["lds_walk_ceiling"]
+    for key in ("kernel", "ubench", "frac", "ubench_source", "node_visits_per_s", "frac_of_seven_instruction_floor"):
+        assert key in c, key
+    assert 0.0 < c["frac"] <= 1.0 and 0.0 < c["frac_of_seven_instruction_floor"] <= 1.0
+    assert abs(c["frac"] - c["ubench"] / c["kernel"]) < 1e-3 and r["frac_le_1"] == c["frac"]
+    assert "live" in c["ubench_source"]
+    assert abs(c["node_visits_per_s"] - 1_000_000 * 1000 * 12 / (r["walk_kernel_ms_avg"] * 1e-3)) / c["node_visits_per_s"] < 1e-3
+
+
+def test_recorded_line_has_every_baseline_configuration():
+    """K1, K2, K5 are driver-run legs of the same line (K3 = the primary figures, K4 = `k4`): time from the
+    in-library hipEvents, the kernel form that ran, byte-model and compulsory fractions, stamped counters, a bitwise check."""
+    cfg = recorded_line()["configs"]
+    assert set(cfg) >= {"K1", "K2", "K3", "K4", "K5", "seconds"} and cfg["seconds"] <= 15.0
+    want_form = {"K1": "qring_split", "K2": "tilering_wide_stream", "K5": "sparse_qring"}
+    for k in ("K1", "K2", "K5"):
+        leg = cfg[k]
+        assert "error" not in leg, leg
+        for key in ("workload", "strategy", "kernel_form", "ms", "samples_per_s", "stream_slots", "ring_rows", "rows_checked",
+                    "bitwise_equal_to_cpu_oracle", "roofline"):
+            assert key in leg, (k, key)
+        assert leg["kernel_form"] == want_form[k] and leg["rows_checked"] >= 2048 and leg["bitwise_equal_to_cpu_oracle"] is True
+        assert leg["ms"] > 0 and abs(leg["samples_per_s"] - int(leg["workload"].split(" rows")[0].split()[-1]) / (leg["ms"] * 1e-3)) / leg["samples_per_s"] < 1e-2
+        rl = leg["roofline"]
+        assert 0.0 < rl["compulsory_frac"] <= 1.0 and rl["frac"] > 0.0
+        assert rl["counters"] is None or (rl["counters"]["src_hash"] and 0.0 < max(rl["counters"]["busy"].values()) <= 1.0)
+    assert cfg["K2"]["stream_slots"] >= 4 and cfg["K3"]["kernel_form"].startswith("qring_region")
+
+
 def test_bench_source_keeps_the_oracle_out_of_the_timed_regions():
     """bench.py reaches the oracle through one accessor, used by the cpu_baseline leg and by the checks of the K4 legs'
     results; neither sits inside a timed region (`timed(`, or between the fences of the primary loop)."""
@@ -49,14 +86,14 @@ def test_bench_source_keeps_the_oracle_out_of_the_timed_regions():
 
 
 def test_committed_pmc_profile_belongs_to_these_kernel_sources():
-    """roofline.traffic / roofline.physical come from profiles/r03/pmc_k3.json only while its stamp matches the device
+    """roofline.traffic / roofline.physical come from profiles/r04/pmc_k3.json only while its stamp matches the device
     sources in the tree (bench.kernel_source_hash); a kernel edit without a fresh tools/pmc.sh run turns this red."""
     import sys
 
     sys.path.insert(0, ROOT)
     import bench
 
-    prof = json.load(open(os.path.join(ROOT, "profiles", "r03", "pmc_k3.json")))
+    prof = json.load(open(os.path.join(ROOT, "profiles", "r04", "pmc_k3.json")))
     assert prof["src_hash"] == bench.kernel_source_hash()
     phys = bench.physical_ceilings(prof, 3.7, 0.77, 1_000_000, 256)
     for kern in ("walk", "quantise"):

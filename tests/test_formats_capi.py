@@ -272,3 +272,43 @@ def test_product_never_touches_the_oracle():
                 assert "oracle" not in text.lower(), f"{os.path.join(dirpath, fn)} mentions the oracle"
     syms = os.popen(f"nm -D --undefined-only {os.path.join(pkg, 'libtahoe_amd.so')} 2>/dev/null").read()
     assert "oracle_" not in syms
+
+
+def test_histogram_style_generator_properties(ta):
+    """tahoe_synth_forest_hist / tahoe_synth_data_hist (the realistic-forest generator): deterministic, valid forests, at most
+    max_bins distinct thresholds per feature, Zipf-skewed feature usage, early leaves, no dead branch on data drawn from the
+    same feature distributions (checked with the oracle on the CPU)."""
+    T, D, C, R = 60, 7, 40, 3000
+    a = ta.synth_forest_hist(T, D, C, seed=5, feature_seed=9, max_bins=63, zipf_s=1.1, leaf_prob=0.03, scale_decades=4.0)
+    b = ta.synth_forest_hist(T, D, C, seed=5, feature_seed=9, max_bins=63, zipf_s=1.1, leaf_prob=0.03, scale_decades=4.0)
+    assert a.tobytes() == b.tobytes()
+    assert a.tobytes() != ta.synth_forest_hist(T, D, C, seed=6, feature_seed=9, max_bins=63, zipf_s=1.1, leaf_prob=0.03, scale_decades=4.0).tobytes()
+    x = ta.synth_data_hist(R, C, seed=3, feature_seed=9, scale_decades=4.0, missing_prob=0.01)
+    assert x.tobytes() == ta.synth_data_hist(R, C, seed=3, feature_seed=9, scale_decades=4.0, missing_prob=0.01).tobytes()
+    # ranks generate disjoint row ranges of the same stream
+    assert ta.synth_data_hist(100, C, seed=3, feature_seed=9, scale_decades=4.0, missing_prob=0.01, first_row=500).tobytes() == x[500:600].tobytes()
+    inner = a["bits"] >= 0
+    fid = a["bits"] & ((1 << 30) - 1)
+    per_tree = ta.capi.tree_num_nodes(D)
+    assert not inner.reshape(T, per_tree)[:, per_tree // 2:].any()  # the bottom level is all leaves
+    assert (fid[inner] < C).all()
+    distinct = [np.unique(a["val"][inner & (fid == f)]).size for f in range(C)]
+    assert 1 <= max(distinct) <= 63
+    use = np.sort(np.bincount(fid[inner], minlength=C))[::-1]
+    assert use[0] > 4 * np.median(use)  # skewed usage
+    want, leaf = oracle.predict(a, T, D, x, -999.0, want_leaf=True)
+    level = np.floor(np.log2(leaf.astype(np.float64) + 1.0))
+    assert level.min() < D and level.mean() > 2.0  # early leaves exist, and trees are not trivial
+    # the scales differ by decades across features
+    spread = np.nanstd(np.where(x == np.float32(-999.0), np.nan, x), axis=0)
+    assert spread.max() / spread.min() > 100.0
+    # no dead branch: both children of well-visited internal nodes are reached (root level of every tree with an internal root)
+    root_inner = inner.reshape(T, per_tree)[:, 0]
+    went_right = (leaf >= 2)  # heap index 2 = the right child's subtree starts ... use the level-1 ancestor
+    anc = leaf.astype(np.int64) + 1
+    while (anc > 3).any():
+        anc = np.where(anc > 3, anc >> 1, anc)
+    share_right = (anc == 3).mean(axis=0)
+    assert ((share_right[root_inner] > 0.0) & (share_right[root_inner] < 1.0)).mean() > 0.9
+    with pytest.raises(ta.TahoeError):
+        ta.synth_forest_hist(1, 3, 0)

@@ -972,3 +972,82 @@ def test_wide_rows_form_rule_looks_at_key_resolution(env, monkeypatch, case):
     g.check()
     assert np.array_equal(bits(leaf.cpu().numpy()), want_leaf) and np.array_equal(bits(sums.cpu().numpy()), bits(want))
     g.close()
+
+
+HIST_SHAPES = [
+    # T, D, C, R, max_bins, zipf_s, scale_decades
+    (200, 8, 28, 4000, 255, 1.0, 3.0),     # HIGGS-like width
+    (120, 6, 128, 3001, 63, 1.2, 4.0),     # few bins, strongly skewed usage
+    (60, 10, 256, 2500, 255, 0.8, 2.0),    # deep trees on K3's width: early leaves everywhere
+    (40, 7, 1024, 900, 255, 1.0, 5.0),     # wide rows with features on very different scales
+    (500, 5, 54, 2000, 32, 1.5, 0.0),      # covtype-like: many shallow trees, one scale
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,D,C,R,bins,zipf,decades", HIST_SHAPES)
+def test_histogram_style_forests(env, T, D, C, R, bins, zipf, decades):
+    """Forests in the style of histogram-trained GBDT models (tahoe_synth_forest_hist: <= 255 quantile thresholds per feature,
+    Zipf-skewed feature usage, skewed branch probabilities, early leaves, features on different scales and of different
+    shapes incl. integer counts against half-integer thresholds), rows drawn from the same feature distributions: every
+    strategy against the oracle, leaf indices and sums bit for bit."""
+    ta = env[0]
+    nodes = ta.synth_forest_hist(T, D, C, seed=300 + T, feature_seed=17, max_bins=bins, zipf_s=zipf, leaf_prob=0.02, scale_decades=decades)
+    data = ta.synth_data_hist(R, C, seed=400 + R, feature_seed=17, scale_decades=decades, missing_prob=0.02, missing=MISSING)
+    data[::97, ::5] = np.nan
+    want, leaf = run_case(env, nodes, T, D, C, data)
+    level = np.floor(np.log2(leaf.astype(np.float64) + 1.0))
+    assert level.min() < D, "case must contain leaves above the bottom level"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,D,C,R,bins,missing_prob", [
+    (200, 8, 64, 40_003, 254, 0.02),     # several waves' worth of 384-row tiles + a ragged remainder, missing values (MS walk)
+    (120, 10, 256, 33_000, 255, 0.0),    # K3's width; the generator caps at 255 edges, the group's busiest feature decides the form
+    (300, 6, 28, 100_000, 63, 0.0),      # HIGGS-like width: most of every region is empty
+    (40, 12, 128, 20_000, 254, 0.01),    # deep trees: 10-level tops + bottom blocks, early leaves
+])
+def test_qring_on_8bit_codes(env, monkeypatch, T, D, C, R, bins, missing_prob):
+    """Forests whose features each see <= 254 distinct thresholds (histogram-trained models) are quantised to u8 rank codes for
+    batches large enough for whole tiles: 128-row regions, 384-row tiles, six chains per lane (qring_kernel<..., CODE8>).  Leaf
+    indices, sums and continued sums against the oracle; the u16 form (TAHOE_QRING_CODE8=0) gives the same bits."""
+    ta, oracle, torch = env
+    monkeypatch.delenv("TAHOE_QRING_CODE8", raising=False)
+    nodes = ta.synth_forest_hist(T, D, C, seed=500 + T, feature_seed=23, max_bins=bins, zipf_s=1.0, leaf_prob=0.02, scale_decades=3.0)
+    data = ta.synth_data_hist(R, C, seed=600 + T, feature_seed=23, scale_decades=3.0, missing_prob=missing_prob, missing=MISSING)
+    if missing_prob:
+        data[5::211, ::3] = np.nan
+    inner = nodes["bits"] >= 0
+    fid = nodes["bits"] & ((1 << 30) - 1)
+    most = max(np.unique(nodes["val"][inner & (fid == f)]).size for f in range(C))
+    f = ta.Forest(nodes, T, D, C, missing=MISSING)
+    f.set_strategy(ta.STRATEGY_QRING)
+    want8 = most <= 254
+    assert (f.kernel_form(R) == "qring_region8") == want8, (most, f.kernel_form(R))
+    assert f.info().qring_tile_rows == (384 if want8 else 192)
+    # small batches of forests with enough trees keep the u16 tree slices (a slice must still give every walker a few trees)
+    assert f.kernel_form(1000) == ("qring_split" if T >= 120 else "qring_region8" if want8 else "qring_region2")
+    want, want_leaf = oracle.predict(nodes, T, D, data, MISSING, want_leaf=True, threads=8)
+    x = torch.from_numpy(data).cuda()
+    for _ in range(2):
+        leaf, sums = f.predict_leaf_idx(x)
+        raw = f.predict_raw(x)
+        f.check()
+        assert np.array_equal(bits(leaf.cpu().numpy()), want_leaf)
+        assert np.array_equal(bits(sums.cpu().numpy()), bits(want)) and np.array_equal(bits(raw.cpu().numpy()), bits(want))
+    start = np.linspace(-1.0, 1.0, R).astype(np.float32)
+    acc = f.predict_accumulate(x, torch.from_numpy(start.copy()).cuda())
+    f.check()
+    assert np.array_equal(bits(acc.cpu().numpy()), bits(oracle.predict_continue(nodes, T, D, data, MISSING, start)))
+    small = f.predict_raw(x[:1000].contiguous())  # then a small batch on the same handle (u16 codes in the same workspace), then large again
+    assert np.array_equal(bits(small.cpu().numpy()), bits(want[:1000]))
+    assert np.array_equal(bits(f.predict_raw(x).cpu().numpy()), bits(want))
+    f.check()
+    f.close()
+    monkeypatch.setenv("TAHOE_QRING_CODE8", "0")
+    g = ta.Forest(nodes, T, D, C, missing=MISSING)
+    g.set_strategy(ta.STRATEGY_QRING)
+    assert g.kernel_form(R) != "qring_region8"
+    assert np.array_equal(bits(g.predict_raw(x).cpu().numpy()), bits(want))
+    g.check()
+    g.close()

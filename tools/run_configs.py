@@ -16,53 +16,18 @@ sys.path.insert(0, ROOT)
 import tahoe_amd as ta  # noqa: E402
 from oracle import oracle  # noqa: E402
 
-MISSING = -999.0
-HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md)
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r03")
+import bench  # noqa: E402  (the byte model, the counter summaries and the workloads are bench.py's)
+
+MISSING = bench.MISSING
 
 
 def roofline(ms, rows, cols, b, trees, len_sum_per_row, node_bytes, n_nodes, cfg, leaf_bytes=None):
-    """SURVEY.md 8(d) for one configuration: the reference's traversal byte model made exact -- per (row, tree) `len` internal
-    visits of one node record (`node_bytes` = 4 + b for the dense SoA format, 12 for sparse_node_t) and one 4-byte feature, plus
-    the leaf record; plus the row once and the prediction -- over the measured time and the HBM peak; the compulsory bytes (rows +
-    forest + predictions once) the same way; and, from a stamped counter profile of this configuration (tools/pmc_script.sh over
-    tools/pmc_target.py), the HBM-side bytes the counters saw and the busiest unit."""
-    leaf_bytes = node_bytes if leaf_bytes is None else leaf_bytes
-    alg = rows * (len_sum_per_row * (node_bytes + 4) + trees * leaf_bytes + cols * 4 + 4)
-    comp = rows * cols * 4 + n_nodes * node_bytes + rows * 4
-    t = ms * 1e-3
-    out = {"bound": "hbm", "peak": HBM_PEAK / 1e9, "unit": "GB/s", "algorithmic_bytes": int(alg), "achieved": round(alg / t / 1e9, 1),
-           "frac": round(alg / t / HBM_PEAK, 4), "compulsory_bytes": int(comp), "compulsory_frac": round(comp / t / HBM_PEAK, 5),
-           "mean_path_len": round(len_sum_per_row / trees, 3), "bits_bytes": b}
-    try:
-        import bench
-        prof = json.load(open(os.path.join(PROFILE_DIR, "pmc_%s.json" % cfg.lower())))
-        n = int(prof["script"].split()[-1])
-        ks = [v for k, v in prof["kernels"].items() if "bucket_index" not in k]
-        tot = lambda c: sum(v.get(c, 0.0) * v["launches"] for v in ks) / n  # per predict
-        cyc = tot("GRBM_GUI_ACTIVE") / 8.0
-        cus = prof.get("num_cus", 256)
-        vmem = max(tot("SQ_ACTIVE_INST_VMEM"), tot("SQ_INSTS_VMEM_RD"))
-        units = {"vector_issue": (tot("SQ_ACTIVE_INST_VALU") + tot("SQ_ACTIVE_INST_LDS") + vmem) * 4.0 / (cus * 4 * cyc),
-                 "valu": tot("SQ_ACTIVE_INST_VALU") * 4.0 / (cus * 4 * cyc), "lds_array": tot("SQ_LDS_IDX_ACTIVE") / (cus * cyc),
-                 "texture_addr": tot("TA_TA_BUSY") / (cus * cyc), "texture_data": tot("TD_TD_BUSY") / (cus * cyc)}
-        hbm = (tot("FETCH_SIZE") + tot("WRITE_SIZE")) * 1024.0
-        out["counters"] = {"profile": "profiles/r03/pmc_%s.json" % cfg.lower(), "src_hash_matches_tree": prof["src_hash"] == bench.kernel_source_hash(),
-                           "kernels_per_predict": round(sum(v["launches"] for v in ks) / n, 2),
-                           "kernel_ms_profiled": round(cyc / (prof.get("clock_ghz", 2.4) * 1e6), 4),
-                           "hbm_bytes_raw": int(hbm), "hbm_frac_raw": round(hbm / t / HBM_PEAK, 4),
-                           "hbm_note": "FETCH_SIZE + WRITE_SIZE, raw (FETCH_SIZE counts half of wide coalesced reads on gfx950)",
-                           "l2_to_l1_bytes": int(tot("TCP_TCC_READ_REQ") * 128), "busy": {k: round(v, 3) for k, v in units.items()},
-                           "busiest_unit": max(units, key=units.get)}
-    except (OSError, ValueError, KeyError, ZeroDivisionError) as err:
-        out["counters"] = None
-        out["counters_missing"] = repr(err)
+    out = bench.config_roofline(ms, rows, cols, trees, len_sum_per_row, node_bytes, n_nodes, cfg, leaf_bytes)
+    out["bits_bytes"] = b
     return out
 
 
-def path_len_sum(leaf_idx):
-    """Internal nodes visited per (row, tree) = level of the leaf the walk ended on = floor(log2(heap index + 1)); summed per row."""
-    return float(np.floor(np.log2(leaf_idx.astype(np.float64) + 1.0)).sum(axis=1).mean())
+path_len_sum = bench.dense_path_len_sum
 
 
 def bits(a):
@@ -180,18 +145,7 @@ def main():
     leaf, sums = f.predict_leaf_idx(x[torch.from_numpy(sample).cuda()].contiguous())
     f.check()
     sizes = np.diff(np.append(tr, sn.size))
-    # path lengths: level of every node of every tree (children lie behind their parent), then the level of each sampled leaf
-    level = np.zeros(sn.size, dtype=np.int32)
-    frontier = tr.astype(np.int64)
-    root_of = np.repeat(tr.astype(np.int64), sizes)
-    lvl = 0
-    while frontier.size:
-        level[frontier] = lvl
-        inner = frontier[sn["bits"][frontier] >= 0]  # is_leaf is the sign bit
-        kids = root_of[inner] + sn["left_idx"][inner]
-        frontier = np.concatenate([kids, kids + 1])
-        lvl += 1
-    len5 = float(level[tr.astype(np.int64)[None, :] + want_leaf.astype(np.int64)].sum(axis=1).mean())
+    len5 = bench.sparse_path_len_sum(sn, tr, want_leaf)
     res["K5"] = {"shape": {"trees": T, "cols": C, "rows": R, "nodes": int(sn.size), "nodes_per_tree_mean": float(sizes.mean()),
                            "nodes_per_tree_max": int(sizes.max())},
                  "strategy": "sparse_" + ta.STRATEGY_NAMES[f.get_strategy(R)], "ms": round(ms, 3), "ms_per_strategy": per_strategy, "samples_per_s": round(R / ms * 1e3),

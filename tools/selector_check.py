@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Strategy selector vs brute-force enumeration (what the reference's SetUp does, BaseTahoeTest.h:652-706, and what
 its analytic model in main.cu:22-80 tries to predict): for a grid of shapes, time every available strategy and
-compare the fastest with TAHOE_STRATEGY_AUTO's choice.  Writes gpurun_out/selector.json."""
+compare the fastest with TAHOE_STRATEGY_AUTO's choice.  Writes gpurun_out/selector.json (--holdout: shapes the rule was not
+fitted on -> selector_holdout.json; --realistic: forests and rows of the histogram-style generator -- <= 255 quantile thresholds
+per feature, Zipf-skewed feature usage, early leaves, features on different scales -> selector_realistic.json).  Every file is
+stamped with the hash of the kernel sources it was measured on."""
 import json
 import os
 import sys
@@ -27,14 +30,30 @@ HOLDOUT = [
 ]
 
 
+# histogram-style forests (tahoe_synth_forest_hist): shapes of the public GBDT benchmarks the reference is run on
+# (run_all_15_examples.sh:51-65: SUSY / HIGGS / covtype / year / epsilon-like widths); trees, depth, cols, rows, max_bins
+REALISTIC = [
+    (500, 8, 18, 500_000, 255), (1000, 6, 28, 500_000, 255), (300, 10, 54, 300_000, 63), (800, 8, 90, 300_000, 255),
+    (400, 12, 256, 300_000, 255), (200, 8, 2000, 50_000, 255),
+]
+
+
 def main():
+    import bench
+
     out = []
-    holdout = "--holdout" in sys.argv
-    for (T, D, C, R) in (HOLDOUT if holdout else SHAPES):
-        nodes = ta.synth_forest(T, D, C, seed=7)
-        x = torch.from_numpy(ta.synth_data(R, C, seed=8)).cuda()
+    holdout, realistic = "--holdout" in sys.argv, "--realistic" in sys.argv
+    for shape in (REALISTIC if realistic else HOLDOUT if holdout else SHAPES):
+        T, D, C, R = shape[:4]
+        if realistic:
+            nodes = ta.synth_forest_hist(T, D, C, seed=7, feature_seed=11, max_bins=shape[4], zipf_s=1.0, leaf_prob=0.02, scale_decades=3.0)
+            x = torch.from_numpy(ta.synth_data_hist(R, C, seed=8, feature_seed=11, scale_decades=3.0)).cuda()
+        else:
+            nodes = ta.synth_forest(T, D, C, seed=7)
+            x = torch.from_numpy(ta.synth_data(R, C, seed=8)).cuda()
         f = ta.Forest(nodes, T, D, C, missing=-999.0)
         auto = f.get_strategy(R)
+        auto_form = f.kernel_form(R)
         sums = torch.empty(R, dtype=torch.float32, device="cuda")
         times = {}
         for s in range(1, 6):
@@ -53,11 +72,18 @@ def main():
             times[ta.STRATEGY_NAMES[s]] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
         best = min(times, key=times.get)
         out.append({"trees": T, "depth": D, "cols": C, "rows": R, "ms": times, "best": best,
-                    "auto": ta.STRATEGY_NAMES[auto], "auto_over_best": round(times[ta.STRATEGY_NAMES[auto]] / times[best], 3)})
+                    "auto": ta.STRATEGY_NAMES[auto], "auto_kernel_form": auto_form,
+                    "auto_over_best": round(times[ta.STRATEGY_NAMES[auto]] / times[best], 3)})
+        if realistic:
+            out[-1]["max_bins"] = shape[4]
         print(out[-1], flush=True)
         f.close()
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "selector_holdout.json" if holdout else "selector.json"), "w"), indent=1)
+    name = "selector_realistic.json" if realistic else "selector_holdout.json" if holdout else "selector.json"
+    json.dump({"src_hash": bench.kernel_source_hash(), "generator": "tahoe_synth_forest_hist / tahoe_synth_data_hist" if realistic else
+               "tahoe_synth_forest / tahoe_synth_data (uniform)", "auto_is_fastest_on": sum(1 for e in out if e["auto"] == e["best"]),
+               "worst_auto_over_best": max(e["auto_over_best"] for e in out), "shapes": out},
+              open(os.path.join(ROOT, "gpurun_out", name), "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #define CHECK(x)                                                                         \
@@ -168,7 +169,36 @@ static void run(const uint16_t *tile, const uint32_t *tops, uint32_t *out)
     CHECK(hipEventDestroy(e1));
 }
 
-int main()
+// --kernel-shape: only the shape the product's K3 walk runs (14 walker waves x 3 chains on 64-row regions, child pairs,
+// unrolled), best of 5 launches, as one JSON line: bench.py runs this as a child process for roofline.physical.walk.lds_walk_ceiling.
+template <int NW, int K>
+static void run_json(const uint16_t *tile, const uint32_t *tops, uint32_t *out)
+{
+    const int lds = COLS * 128 * K + NW * 4096;
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&qwalk<NW, K, 0, true, 128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount < 256 ? prop.multiProcessorCount : 256;  // (the output buffer holds 256 workgroups)
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    const int iters = 2400 / K;
+    float best = 1e30f;
+    for (int rep = 0; rep < 6; ++rep) {
+        float ms = 0;
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL((qwalk<NW, K, 0, true, 128, false>), dim3(cus), dim3(NW * 64), lds, 0, tile, tops, iters, out);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep > 0 && ms < best) best = ms;
+    }
+    const double wave_levels_per_cu = (double)NW * iters * K * LEVELS;  // one workgroup per CU
+    printf("{\"nw\": %d, \"k\": %d, \"cus\": %d, \"ms\": %.4f, \"wave_levels_per_cu\": %.0f, \"ns_per_wave_level_per_cu\": %.5f, "
+           "\"clock_mhz\": %d}\n", NW, K, cus, best, wave_levels_per_cu, best * 1e6 / wave_levels_per_cu, prop.clockRate / 1000);
+}
+
+int main(int argc, char **argv)
 {
     uint64_t s = 99;
     auto rnd = [&]() {
@@ -186,6 +216,10 @@ int main()
     CHECK(hipMalloc(&d_out, 256 * 16 * 64 * 4));
     CHECK(hipMemcpy(d_tile, h_tile.data(), h_tile.size() * 2, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(d_tops, h_tops.data(), h_tops.size() * 4, hipMemcpyHostToDevice));
+    if (argc > 1 && std::string(argv[1]) == "--kernel-shape") {
+        run_json<14, 3>(d_tile, d_tops, d_out);
+        return 0;
+    }
 
     run<15, 2, 0, false>(d_tile, d_tops, d_out);
     run<15, 2, 0, true>(d_tile, d_tops, d_out);
