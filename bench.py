@@ -202,7 +202,7 @@ def config_counters(cfg, ms):
         if prof.get("src_hash") != kernel_source_hash():
             return None
         n = int(prof["script"].split()[-1])
-        ks = [v for k, v in prof["kernels"].items() if "bucket_index" not in k]
+        ks = [v for k, v in prof["kernels"].items() if "bucket_index" not in k and "threshold_keys" not in k]  # (not the create-time kernels)
         tot = lambda c: sum(v.get(c, 0.0) * v["launches"] for v in ks) / n  # per predict
         cyc = tot("GRBM_GUI_ACTIVE") / 8.0
         cus = prof.get("num_cus", 256)
@@ -259,9 +259,10 @@ def sparse_path_len_sum(sn, tr, want_leaf):
     return float(level[tr.astype(np.int64)[None, :] + want_leaf.astype(np.int64)].sum(axis=1).mean())
 
 
-def config_legs(ta, torch, which=("K1", "K2", "K5"), warmup=5, steps=20, check_rows=2048):
-    """BASELINE.json's configurations other than the metric's (K3) and K4, timed on this device after the primary region (never
-    part of `value`): 5 warm-ups + 20 timed predicts with the in-library hipEvents on resident inputs, which kernel form ran,
+def config_legs(ta, torch, which=("K1", "K2", "K5", "KR3"), warmup=5, steps=20, check_rows=2048):
+    """BASELINE.json's configurations other than the metric's (K3) and K4 -- plus KR3, K3's shape from the histogram-style generator
+    (254 thresholds per feature, skewed feature usage, early leaves: what trained models look like; QRING walks it on u8 codes) --
+    timed on this device after the primary region (never part of `value`): 5 warm-ups + 20 timed predicts with the in-library hipEvents on resident inputs, which kernel form ran,
     the byte-model and compulsory-byte fractions, the configuration's stamped counters, and a bitwise check of the timed
     launches' output on >= 2048 rows against the CPU oracle (the checker, called after the timing)."""
     oracle = _oracle()
@@ -298,7 +299,8 @@ def config_legs(ta, torch, which=("K1", "K2", "K5"), warmup=5, steps=20, check_r
             strategy = ta.STRATEGY_NAMES.get(forest.get_strategy(rows), "?")
             leg = {"workload": (f"{cfg}: {T} trees depth {D}, {cols} features, {rows} rows" if kind == "dense" else
                                 f"{cfg}: sparse forest {T} trees depth {K5_SHAPE['min_depth']}-{K5_SHAPE['max_depth']}, {int(sn.size)} nodes, "
-                                f"{cols} features, {rows} rows") + (", through the text file formats" if cfg == "K1" else ""),
+                                f"{cols} features, {rows} rows") + (", through the text file formats" if cfg == "K1" else "") +
+                               (", histogram-style generator (<= 254 thresholds per feature)" if cfg == "KR3" else ""),
                    "strategy": ("sparse_" if kind == "sparse" else "") + strategy, "kernel_form": forest.kernel_form(rows),
                    "ms": round(ms, 4), "ms_source": f"hipEvents inside the library, mean of {len(walk)} predicts (pre-pass + walk)",
                    "prepass_ms": round(float(np.mean(pre)) if len(pre) else 0.0, 4), "ms_min": round(float(np.min(np.asarray(walk) + np.asarray(pre))), 4),

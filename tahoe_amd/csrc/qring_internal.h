@@ -79,8 +79,14 @@ constexpr int kQSlotBytes = 4096;            // LDS per walker: a 10-level top (
 // a ring shorter than the walker count only makes a walker that finishes early wait for the trees before its own.
 constexpr int kRegRows = 64;
 constexpr int kRegBytes = 32768;
-constexpr int kReg3Walkers = 14;
-constexpr int kReg3Ring = 10;
+#ifndef TAHOE_R3_WALKERS
+#define TAHOE_R3_WALKERS 14
+#endif
+#ifndef TAHOE_R3_RING
+#define TAHOE_R3_RING 10
+#endif
+constexpr int kReg3Walkers = TAHOE_R3_WALKERS;
+constexpr int kReg3Ring = TAHOE_R3_RING;
 constexpr int kQMaxTable = 32767;
 // LDS of the region form: K regions of 32 KiB, walker slots, ring
 inline long long qreg_lds_for(int k, int nwalk, int ring, bool code8 = false)
@@ -88,19 +94,21 @@ inline long long qreg_lds_for(int k, int nwalk, int ring, bool code8 = false)
     return (long long)(code8 ? k / 2 : k) * kRegBytes + (long long)nwalk * kQSlotBytes + (long long)ring * k * kRegRows * 4 + (ring + 1) * 4LL;
 }
 // u8 form: six chains (384-row tiles of three 128-row regions) for whole waves of workgroups, two chains (one region) for
-// the remainder; walkers / ring / consumer batch of the 384-row tile (96 KiB + 13 x 4 KiB + 7 x 1.5 KiB = 162,336 B)
+// the remainder; walkers / ring / consumer batch of the 384-row tile: 14 / 5 / 2 (96 KiB + 14 x 4 KiB + 5 x 1.5 KiB = 163,352 B); KR3
+// (profiles/r04/tune_q8.txt): 13 / 7 / 3 2.98 ms, 14 / 5 / 2 2.79, 12 / 10 / 4 2.96, 12 / 10 / 5 2.94
 #ifndef TAHOE_Q8_WALKERS
-#define TAHOE_Q8_WALKERS 13
+#define TAHOE_Q8_WALKERS 14
 #endif
 #ifndef TAHOE_Q8_RING
-#define TAHOE_Q8_RING 7
+#define TAHOE_Q8_RING 5
 #endif
 #ifndef TAHOE_Q8_BATCH
-#define TAHOE_Q8_BATCH 3
+#define TAHOE_Q8_BATCH 2
 #endif
 constexpr int kReg8Walkers = TAHOE_Q8_WALKERS, kReg8Ring = TAHOE_Q8_RING, kReg8Batch = TAHOE_Q8_BATCH;
 #ifndef TAHOE_Q8_COST
-#define TAHOE_Q8_COST 205  // time of a 384-row u8 tile in percent of a 128-row u8 tile (first estimate from T(K) = 1.9 + 1.06 K)
+#define TAHOE_Q8_COST 218  // time of a 384-row u8 tile in percent of a 128-row u8 tile: KR3, 983,040 rows, 10 waves of 384-row tiles 2.665 ms
+                           // against 30 waves of 128-row tiles 3.672 ms (profiles/r04/q8_cost.txt)
 #endif
 constexpr size_t kReg8Cost = TAHOE_Q8_COST;
 // Region form: 192-row tiles (three chains, 14 walkers) take 1.33 x the time of 128-row tiles (two chains, 15 walkers),

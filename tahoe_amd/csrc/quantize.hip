@@ -387,6 +387,13 @@ __global__ void __launch_bounds__(kQuantPairThreads)
     if (__ballot(saw_missing) != 0 && (threadIdx.x & 63) == 0) atomicOr(&chunk_flags[chunk], 1u);
 }
 
+// Features per workgroup of the many-features form: 4 x kQuantMultiMax at most (make QMULTI=4 keeps 16; 8 = 32 features: a row's
+// 32 values are one whole 128-byte line, read by eight adjacent lanes).
+#ifndef TAHOE_QUANT_MULTI_MAX
+#define TAHOE_QUANT_MULTI_MAX 4  // 32 features per workgroup measured slower (profiles/r04/tune_qmulti.txt: KR3 0.47 -> 0.61 ms, K2 0.94 -> 1.10)
+#endif
+constexpr int kQuantMultiMax = TAHOE_QUANT_MULTI_MAX;
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // Bucketed quantiser tables for one group (see quantize_bucket_pair_kernel).  Leaves g.buckets = 0 when the form is
@@ -554,8 +561,8 @@ tahoe_status quantize_build_tables(tahoe_forest *f, const std::vector<std::vecto
     {
         const char *e = getenv("TAHOE_QUANT_MULTI");  // experiments: 0 keeps the pair kernels
         if (!(e && atoi(e) == 0))
-            for (int qd : {4, 2})
-                if (cols % (4 * qd) == 0 && (long long)4 * qd * max_size * 4 <= f->lds_limit - 256) {
+            for (int qd : {kQuantMultiMax, 4, 2})
+                if (qd <= kQuantMultiMax && cols % (4 * qd) == 0 && (long long)4 * qd * max_size * 4 <= f->lds_limit - 256) {
                     g.multi_q = qd;
                     break;
                 }
@@ -585,7 +592,7 @@ void quantize_free_tables(tahoe_qgroup &g)
 
 hipError_t quantize_allow_lds(const tahoe_forest *f)
 {
-    for (const void *k : {(const void *)&quantize_multi_kernel<4>, (const void *)&quantize_multi_kernel<2>,
+    for (const void *k : {(const void *)&quantize_multi_kernel<8>, (const void *)&quantize_multi_kernel<4>, (const void *)&quantize_multi_kernel<2>,
                           (const void *)&quantize_bucket_pair_kernel, (const void *)&quantize_pair_kernel,
                           (const void *)&quantize_kernel<1>}) {
         const hipError_t e = allow_max_lds(k, f->lds_limit);
@@ -615,7 +622,11 @@ tahoe_status quantize_launch(tahoe_forest *f, const tahoe_qgroup &g, const float
     const size_t chunks = (rows + ((size_t)1 << cshift) - 1) >> cshift;
     const size_t qgrid = chunks * fgroups;
     if (qgrid > 0x7fffffffu) return fail(TAHOE_ERR_INVALID_ARG, "too many rows x cols for one launch");
-    if (multi_ok && g.multi_q == 4)
+    if (multi_ok && g.multi_q == 8)
+        hipLaunchKernelGGL(quantize_multi_kernel<8>, dim3((unsigned)qgrid), dim3(kQuantPairThreads),
+                           (size_t)32 * std::max(g.max_table, 1) * 4, stream, data, g.tables, g.offsets, q->xq, q->chunk_flags,
+                           rows, f->p.num_cols, f->p.missing, std::max(g.max_table, 1), trs, cshift, perm);
+    else if (multi_ok && g.multi_q == 4)
         hipLaunchKernelGGL(quantize_multi_kernel<4>, dim3((unsigned)qgrid), dim3(kQuantPairThreads),
                            (size_t)16 * std::max(g.max_table, 1) * 4, stream, data, g.tables, g.offsets, q->xq, q->chunk_flags,
                            rows, f->p.num_cols, f->p.missing, std::max(g.max_table, 1), trs, cshift, perm);

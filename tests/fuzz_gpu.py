@@ -34,13 +34,23 @@ while time.time() < t_end:
     else:
         T = int(rng.choice([1, 2, 5, 16, 33, 100, 300])) if not BIG else int(rng.choice([100, 300, 700]))
         D = int(rng.choice([0, 1, 2, 3, 5, 8, 10, 12])) if C <= 600 else int(rng.choice([2, 3, 6, 8, 10]))
-        nodes = ta.synth_forest(T, D, C, seed=int(rng.integers(1 << 30)), leaf_prob=float(rng.choice([0.0, 0.1, 0.3])))
+        hist = rng.random() < 0.35  # histogram-style forest and rows (few thresholds per feature: QRING's u8 form on large batches)
+        if hist:
+            fseed, dec, bins = int(rng.integers(1 << 30)), float(rng.choice([0.0, 2.0, 5.0])), int(rng.choice([3, 31, 254, 255, 1000]))
+            nodes = ta.synth_forest_hist(T, D, C, seed=int(rng.integers(1 << 30)), feature_seed=fseed, max_bins=bins,
+                                         zipf_s=float(rng.choice([0.0, 1.0, 2.0])), leaf_prob=float(rng.choice([0.0, 0.05])), scale_decades=dec)
+            data = ta.synth_data_hist(R, C, seed=int(rng.integers(1 << 30)), feature_seed=fseed, scale_decades=dec, missing_prob=mp, missing=MISSING)
+            if mp:
+                data[::7, ::3] = np.nan
+            x = torch.from_numpy(data).cuda()
+        else:
+            nodes = ta.synth_forest(T, D, C, seed=int(rng.integers(1 << 30)), leaf_prob=float(rng.choice([0.0, 0.1, 0.3])))
         want, want_leaf = oracle.predict(nodes, T, D, data, MISSING, want_leaf=True, threads=8)
         stream_form = C > 512 and rng.random() < 0.5  # TILERING as the row-streaming kernel (read at create)
         os.environ["TAHOE_WSTREAM"] = "1" if stream_form else "0"
         f = ta.Forest(nodes, T, D, C, missing=MISSING)
         strategies = [ta.STRATEGY_AUTO, ta.STRATEGY_DIRECT, ta.STRATEGY_ROWTILE, ta.STRATEGY_TILEBLOCK, ta.STRATEGY_TILERING, ta.STRATEGY_QRING]
-        desc = f"dense T={T} D={D} C={C} R={R} missing={mp}" + (" wstream" if stream_form else "")
+        desc = f"dense T={T} D={D} C={C} R={R} missing={mp}" + (" wstream" if stream_form else "") + (f" hist bins={bins} decades={dec}" if hist else "")
     for s in strategies:
         try:
             f.set_strategy(s)

@@ -7,6 +7,7 @@ two independent kernels agree, row-permutation equivariance, a ragged prefix equ
   K2  SVHN-like: 500 trees x depth 8, 3072 features, 100 k rows (wide rows: 16-row tiles, several trees per wave)
   K4  8000 trees x depth 12, 256 features, 1 M rows on ONE GPU (tree groups), and as 8 tree shards combined the three ways
   K5  irregular sparse forest: 2000 trees of depth 4..24, 256 features, 200 k rows
+  KR3 K3's shape from the histogram-style generator (<= 254 thresholds per feature): QRING on u8 codes, every row
 """
 import os
 
@@ -199,3 +200,39 @@ def test_k5_irregular_sparse_forest(env):
     one, _ = oracle.sparse_predict(sn, tr, data[:1000], MISSING)
     assert not np.array_equal(bits(cont), bits(one))  # it did start from 0.5 ...
     assert np.allclose(cont, one + 0.5, rtol=0, atol=2e-4)  # ... and is the same sum shifted (bit-exact check: test_gpu_parity)
+
+
+def test_kr3_histogram_style_forest_at_k3_size(env, monkeypatch):
+    """KR3: K3's shape (1000 trees of depth 12, 256 features, 1 M rows) from the histogram-style generator -- 254 quantile
+    thresholds per feature, Zipf-skewed feature usage, skewed branch probabilities, early leaves, 0.1 % missing values: what
+    trained models look like (run_all_15_examples.sh:51-65).  AUTO walks it on u8 rank codes in 384-row tiles, ONE tree group
+    (round 3 cut such forests by node counts); EVERY row against the oracle, the u16 form and DIRECT on every row / a slice."""
+    ta, oracle, torch = env
+    monkeypatch.delenv("TAHOE_QRING_CODE8", raising=False)
+    T, D, C, R = 1000, 12, 256, 1_000_000
+    nodes = ta.synth_forest_hist(T, D, C, seed=42, feature_seed=7, max_bins=254, zipf_s=1.0, leaf_prob=0.02, scale_decades=3.0)
+    data = ta.synth_data_hist(R, C, seed=43, feature_seed=7, scale_decades=3.0, missing_prob=0.001, missing=MISSING)
+    x = torch.from_numpy(data).cuda()
+    forest = ta.Forest(nodes, T, D, C, missing=MISSING)
+    info = forest.info()
+    assert forest.get_strategy(R) == ta.STRATEGY_QRING and forest.kernel_form(R) == "qring_region8"
+    assert info.qring_groups == 1 and info.qring_tile_rows == 384
+    got = forest.predict_raw(x).cpu().numpy()
+    forest.check()
+    want_all, _ = oracle.predict(nodes, T, D, data, MISSING, threads=min(os.cpu_count() or 8, 256))  # every row: 1.2e10 visits at most
+    assert np.array_equal(bits(got), bits(want_all))
+    idx = strided(R, 4001)
+    want, want_leaf = oracle.predict(nodes, T, D, data[idx], MISSING, want_leaf=True, threads=8)
+    leaf, sums = forest.predict_leaf_idx(x[torch.from_numpy(idx).cuda()].contiguous())
+    assert np.array_equal(bits(leaf.cpu().numpy()), want_leaf) and np.array_equal(bits(sums.cpu().numpy()), bits(want))
+    forest.set_strategy(ta.STRATEGY_DIRECT)  # an independent kernel (float32 compares) on a slice
+    assert np.array_equal(bits(forest.predict_raw(x[:100_000].contiguous()).cpu().numpy()), bits(got[:100_000]))
+    forest.set_strategy(ta.STRATEGY_AUTO)
+    properties(torch, forest, x, got, ragged=333_333)
+    forest.close()
+    monkeypatch.setenv("TAHOE_QRING_CODE8", "0")  # the u16 form of the same forest, every row
+    f16 = ta.Forest(nodes, T, D, C, missing=MISSING)
+    assert f16.kernel_form(R).startswith("qring_region") and f16.kernel_form(R) != "qring_region8"
+    assert np.array_equal(bits(f16.predict_raw(x).cpu().numpy()), bits(got))
+    f16.check()
+    f16.close()

@@ -56,9 +56,9 @@ def test_recorded_line_has_every_baseline_configuration():
     """K1, K2, K5 are driver-run legs of the same line (K3 = the primary figures, K4 = `k4`): time from the
     in-library hipEvents, the kernel form that ran, byte-model and compulsory fractions, stamped counters, a bitwise check."""
     cfg = recorded_line()["configs"]
-    assert set(cfg) >= {"K1", "K2", "K3", "K4", "K5", "seconds"} and cfg["seconds"] <= 15.0
-    want_form = {"K1": "qring_split", "K2": "tilering_wide_stream", "K5": "sparse_qring"}
-    for k in ("K1", "K2", "K5"):
+    assert set(cfg) >= {"K1", "K2", "K3", "K4", "K5", "KR3", "seconds"} and cfg["seconds"] <= 15.0
+    want_form = {"K1": "qring_split", "K2": "tilering_wide_stream", "K5": "sparse_qring", "KR3": "qring_region8"}
+    for k in ("K1", "K2", "K5", "KR3"):
         leg = cfg[k]
         assert "error" not in leg, leg
         for key in ("workload", "strategy", "kernel_form", "ms", "samples_per_s", "stream_slots", "ring_rows", "rows_checked",

@@ -316,12 +316,16 @@ def test_region_form_two_and_three_chains(env, monkeypatch):
     data[2000, 3] = MISSING
     want, want_leaf = oracle.predict(nodes, T, D, data, MISSING, want_leaf=True, threads=4)
     x = torch.from_numpy(data).cuda()
-    for env_set in ({"TAHOE_QRING_CHAINS": "3"}, {"TAHOE_QRING_CHAINS": "2"}, {"TAHOE_QRING_REGIONS": "0"}, {}):
+    # (this forest has < 255 thresholds per feature: left alone, large tiles would be walked on u8 codes -- the last three settings;
+    # TAHOE_QRING_CODE8=0 keeps the u16 forms this test is about)
+    u16 = {"TAHOE_QRING_CODE8": "0"}
+    for env_set in (dict(u16, TAHOE_QRING_CHAINS="3"), dict(u16, TAHOE_QRING_CHAINS="2"), dict(u16, TAHOE_QRING_REGIONS="0"), u16,
+                    {"TAHOE_QRING_CHAINS": "3"}, {"TAHOE_QRING_CHAINS": "2"}, {}):
         for k, v in env_set.items():
             monkeypatch.setenv(k, v)
         forest = ta.Forest(nodes, T, D, C, missing=MISSING)
         forest.set_strategy(ta.STRATEGY_QRING)
-        assert forest.info().qring_tile_rows == (128 if "TAHOE_QRING_REGIONS" in env_set else 192)
+        assert forest.info().qring_tile_rows == (128 if "TAHOE_QRING_REGIONS" in env_set else 192 if "TAHOE_QRING_CODE8" in env_set else 384)
         for rows in (1, 63, 64, 65, 191, 192, 193, 385, 577, 1000, R):
             leaf, sums = forest.predict_leaf_idx(x[:rows].contiguous())
             raw = forest.predict_raw(x[:rows].contiguous())
@@ -337,11 +341,14 @@ def test_region_form_two_and_three_chains(env, monkeypatch):
             monkeypatch.delenv(k)
 
 
-def test_batches_walked_as_waves_of_192_row_tiles_plus_a_128_row_remainder(env):
+@pytest.mark.parametrize("code8", ["0", "1"])
+def test_batches_walked_as_waves_of_192_row_tiles_plus_a_128_row_remainder(env, monkeypatch, code8):
     """Mid-size batches of the region form run as whole waves of 192-row tiles followed by a remainder of 128-row tiles
-    (two launches over disjoint row ranges; 125 k rows on 256 CUs: 98,304 + 26,696).  Every row against the oracle, leaf
-    indices on the rows around the cut, running sums continued across it."""
+    (two launches over disjoint row ranges; 125 k rows on 256 CUs: 98,304 + 26,696) -- on u8 codes (code8 = 1; this forest has
+    ~120 thresholds per feature) as whole waves of 384-row tiles + a remainder of 128-row tiles (125 k rows: the same cut).
+    Every row against the oracle, leaf indices on the rows around the cut, running sums continued across it."""
     ta, oracle, torch = env
+    monkeypatch.setenv("TAHOE_QRING_CODE8", code8)
     T, D, C, R = 30, 8, 64, 300_000
     nodes = ta.synth_forest(T, D, C, seed=95, leaf_prob=0.02)
     data = ta.synth_data(R, C, seed=96, missing_prob=0.0002, missing=MISSING)
@@ -349,6 +356,7 @@ def test_batches_walked_as_waves_of_192_row_tiles_plus_a_128_row_remainder(env):
     x = torch.from_numpy(data).cuda()
     forest = ta.Forest(nodes, T, D, C, missing=MISSING)
     forest.set_strategy(ta.STRATEGY_QRING)
+    assert forest.kernel_form(125_000) == ("qring_region8" if code8 == "1" else "qring_region_mixed")
     for rows in (110_000, 125_000, 147_457, 250_000, R):
         got = forest.predict_raw(x[:rows].contiguous())
         forest.check()
@@ -383,7 +391,7 @@ def test_small_batches_walked_in_tree_slices(env, monkeypatch):
                 monkeypatch.setenv("TAHOE_QRING_SLICES", slices)
             forest = ta.Forest(nodes, T, D, C, missing=MISSING)
             forest.set_strategy(ta.STRATEGY_QRING)
-            assert forest.info().qring_tile_rows == 192
+            assert forest.info().qring_tile_rows in (192, 384)  # (384: few thresholds per feature, large batches on u8 codes)
             for rows in sorted({1, 65, 128, 129, R}):
                 if rows > R:
                     continue

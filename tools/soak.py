@@ -1,4 +1,4 @@
-"""Soak: many back-to-back predicts of the ring kernels (K3 QRING, K2 wide forms, K5 sparse: quantised and float32), then tahoe_forest_check
+"""Soak: many back-to-back predicts of the ring kernels (K3 QRING, KR3 QRING on u8 codes, K2 wide forms, K5 sparse: quantised and float32), then tahoe_forest_check
 (a bounded LDS wait that ever timed out raises) and a bit-for-bit comparison of the last result with the first."""
 import os, sys, time
 import numpy as np, torch
@@ -32,6 +32,13 @@ x = torch.from_numpy(ta.synth_data(1_000_000, 256, seed=43)).cuda()
 f = ta.Forest(ta.synth_forest(1000, 12, 256, seed=42), 1000, 12, 256, missing=-999.0)
 soak("K3 qring", f, x, 200 if QUICK else 1000)
 f.close()
+# KR3: histogram-style forest on u8 codes (384-row tiles, ring of 5 for 14 walkers: the shortest ring of the library)
+xh = torch.from_numpy(ta.synth_data_hist(1_000_000, 256, seed=43, feature_seed=7, scale_decades=3.0)).cuda()
+f = ta.Forest(ta.synth_forest_hist(1000, 12, 256, seed=42, feature_seed=7, max_bins=254), 1000, 12, 256, missing=-999.0)
+assert f.kernel_form(1_000_000) == "qring_region8"
+soak("KR3 qring on u8 codes", f, xh, 100 if QUICK else 600)
+f.close()
+del xh
 sn, tr = ta.capi.synth_sparse_forest(2000, 256, 4, 24, 0.32, 65535, 44)
 f = ta.capi.SparseForest(sn, tr, 256, missing=-999.0)
 soak("K5 sparse, quantised ring", f, x[:200_000].contiguous(), 40 if QUICK else 100)
