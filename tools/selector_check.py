@@ -33,8 +33,8 @@ HOLDOUT = [
 # histogram-style forests (tahoe_synth_forest_hist): shapes of the public GBDT benchmarks the reference is run on
 # (run_all_15_examples.sh:51-65: SUSY / HIGGS / covtype / year / epsilon-like widths); trees, depth, cols, rows, max_bins
 REALISTIC = [
-    (500, 8, 18, 500_000, 255), (1000, 6, 28, 500_000, 255), (300, 10, 54, 300_000, 63), (800, 8, 90, 300_000, 255),
-    (400, 12, 256, 300_000, 255), (200, 8, 2000, 50_000, 255),
+    (500, 8, 18, 500_000, 254), (1000, 6, 28, 500_000, 254), (300, 10, 54, 300_000, 63), (800, 8, 90, 300_000, 255),
+    (400, 12, 256, 300_000, 254), (200, 8, 2000, 50_000, 254), (2000, 7, 128, 200_000, 254),
 ]
 
 
