@@ -46,6 +46,13 @@
 #ifndef TAHOE_WALK_SLEEP
 #define TAHOE_WALK_SLEEP 16
 #endif
+// ... of the 384-row u8 tile (ring of 5 for 14 walkers of six chains: a walker waits for ring space more often, a tree takes twice as long)
+#ifndef TAHOE_WALK_SLEEP8
+#define TAHOE_WALK_SLEEP8 16
+#endif
+#ifndef TAHOE_CONS_SLEEP8
+#define TAHOE_CONS_SLEEP8 1
+#endif
 
 namespace tahoe {
 
@@ -149,7 +156,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                     dead = true;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(TAHOE_CONS_SLEEP);
+                __builtin_amdgcn_s_sleep(CODE8 && K > 2 ? TAHOE_CONS_SLEEP8 : TAHOE_CONS_SLEEP);
             }
             if (dead) break;
             TAHOE_LDS_ACQUIRE();  // the values are read after the flags
@@ -250,7 +257,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                         dead = true;
                         break;
                     }
-                    __builtin_amdgcn_s_sleep(TAHOE_WALK_SLEEP);
+                    __builtin_amdgcn_s_sleep(CODE8 && K > 2 ? TAHOE_WALK_SLEEP8 : TAHOE_WALK_SLEEP);
                 }
             }
             const int e = t % RING;
