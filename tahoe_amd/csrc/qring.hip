@@ -46,9 +46,10 @@
 #ifndef TAHOE_WALK_SLEEP
 #define TAHOE_WALK_SLEEP 16
 #endif
-// ... of the 384-row u8 tile (ring of 5 for 14 walkers of six chains: a walker waits for ring space more often, a tree takes twice as long)
+// ... of the 384-row u8 tile (ring of 5 for 14 walkers of six chains: a walker waits for ring space more often, a tree takes twice as
+// long); KR3 walk (profiles/r04/tune_sleep8.txt): walker 8 / 16 / 32 -> 2.76 / 2.80 / 2.93 ms, consumer 1 / 2 -> 2.80 / 2.79
 #ifndef TAHOE_WALK_SLEEP8
-#define TAHOE_WALK_SLEEP8 16
+#define TAHOE_WALK_SLEEP8 8
 #endif
 #ifndef TAHOE_CONS_SLEEP8
 #define TAHOE_CONS_SLEEP8 1
@@ -71,7 +72,7 @@ namespace tahoe {
 // CODE8 (region form on u8 codes, qring_internal.h): the tile is K / 2 regions of 128 rows, chain k = half k & 1 of region k >> 1;
 // the loop is the same instruction for instruction except that the feature code is a ds_read_u8.
 template <int NWALK, bool WRITE_LEAF, bool LDSX, bool NARROW = false, bool EXCH = false, int K = 2, bool REG = false, int RING = kQRing,
-          bool SPLIT = false, int BATCH = (RING >= 2 * kQBatch ? kQBatch : RING / 2), bool CODE8 = false>
+          bool SPLIT = false, int BATCH = (RING >= 2 * kQBatch ? kQBatch : RING / 2), bool CODE8 = false, bool DEP = false>
 __global__ void __launch_bounds__((NWALK + 1) * 64)
     qring_kernel(const uint16_t *__restrict__ xq, const uint32_t *__restrict__ top, const uint4 *__restrict__ blocks,
                  const uint32_t *__restrict__ qinner, const uint32_t *__restrict__ leaf_orig, float *sums,
@@ -279,6 +280,24 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                 uint32_t node[K];
     #pragma unroll
                 for (int k = 0; k < K; ++k) node[k] = slot[1];
+                if (DEP) {
+                    // Only the chosen child, read AFTER the compare (ds_read_b32 at slot + 4 i): 4 VALU + 2 LDS per chain and
+                    // level instead of 5 + 2 -- no v_cndmask, half the LDS bytes -- at the price of two dependent LDS round trips
+                    // per level.  With six chains per lane and 14 walkers (84 chain-waves per CU) a chain's turn comes round
+                    // every ~500 cycles of an issue-bound CU, so the second round trip hides; with three chains it did not pay
+                    // ("reading only the chosen child ... times the same").
+                    const uint32_t slot_a = (uint32_t)reinterpret_cast<uintptr_t>(slot);
+                    for (int l = 0; l < top_levels - 1; ++l) {
+                        uint32_t xc[K];
+    #pragma unroll
+                        for (int k = 0; k < K; ++k) xc[k] = q_xread<LDSX, NARROW, CS, CODE8>(gx, node[k], pos[k]);
+    #pragma unroll
+                        for (int k = 0; k < K; ++k) {
+                            i[k] = q_descend(i[k], q_right_mask<MS, NARROW, EXCH, MISSC>(xc[k], node[k]));
+                            node[k] = *reinterpret_cast<const uint32_t __attribute__((address_space(3))) *>(slot_a + 4u * i[k]);
+                        }
+                    }
+                } else {
                 // Both children come with one ds_read_b64 issued beside the feature read, ahead of the compare.  (Reading
                 // only the chosen child afterwards -- half the LDS bytes, twice the round trips -- times the same to
                 // 0.5 %: neither LDS bandwidth nor LDS latency bounds this loop, see DESIGN.md.)
@@ -310,6 +329,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                         i[k] = q_descend(i[k], cm);
                         node[k] = __builtin_amdgcn_inverse_ballot_w64(cm) ? pr[k].y : pr[k].x;
                     }
+                }
                 }
     #pragma unroll
                 for (int k = 0; k < K; ++k) {
@@ -704,12 +724,12 @@ static hipError_t q_allow(long long lds)
     for (const void *k : {(const void *)&qring_kernel<15, false, true, true>, (const void *)&qring_kernel<15, true, true, true>,
                           (const void *)&qring_kernel<15, false, true, true, true>, (const void *)&qring_kernel<15, true, true, true, true>,
                           (const void *)&qring_kernel<15, false, true, true, false, 2, true>, (const void *)&qring_kernel<15, true, true, true, false, 2, true>,
-                          (const void *)&qring_kernel<kReg3Walkers, false, true, true, false, 3, true, kReg3Ring>,
-                          (const void *)&qring_kernel<kReg3Walkers, true, true, true, false, 3, true, kReg3Ring>,
+                          (const void *)&qring_kernel<kReg3Walkers, false, true, true, false, 3, true, kReg3Ring, false, kReg3Batch, false, kReg3Dep>,
+                          (const void *)&qring_kernel<kReg3Walkers, true, true, true, false, 3, true, kReg3Ring, false, kReg3Batch, false, kReg3Dep>,
                           (const void *)&qring_kernel<15, false, true, true, false, 2, true, kQRing, true>,
                           (const void *)&qring_kernel<15, true, true, true, false, 2, true, kQRing, true>,
-                          (const void *)&qring_kernel<kReg8Walkers, false, true, true, false, 6, true, kReg8Ring, false, kReg8Batch, true>,
-                          (const void *)&qring_kernel<kReg8Walkers, true, true, true, false, 6, true, kReg8Ring, false, kReg8Batch, true>,
+                          (const void *)&qring_kernel<kReg8Walkers, false, true, true, false, 6, true, kReg8Ring, false, kReg8Batch, true, kReg8Dep>,
+                          (const void *)&qring_kernel<kReg8Walkers, true, true, true, false, 6, true, kReg8Ring, false, kReg8Batch, true, kReg8Dep>,
                           (const void *)&qring_kernel<15, false, true, true, false, 2, true, kQRing, false, kQBatch, true>,
                           (const void *)&qring_kernel<15, true, true, true, false, 2, true, kQRing, false, kQBatch, true>})
         if ((e = allow_max_lds(k, (int)lds)) != hipSuccess) return e;
@@ -1028,7 +1048,7 @@ static tahoe_status qring_reserve_leafbuf(tahoe_forest *f, size_t rows, int tree
 }
 
 template <int NWALK, bool LDSX = true, bool NARROW = false, bool EXCH = false, int K = 2, bool REG = false, int RING = kQRing,
-          bool SPLIT = false, int BATCH = (RING >= 2 * kQBatch ? kQBatch : RING / 2), bool CODE8 = false>
+          bool SPLIT = false, int BATCH = (RING >= 2 * kQBatch ? kQBatch : RING / 2), bool CODE8 = false, bool DEP = false>
 static void q_launch(tahoe_forest *f, const tahoe_qgroup &g, float *sums, const float *sums_in, uint32_t *leaf_out,
                      size_t rows, hipStream_t stream, int cshift, int slices = 1, size_t row_begin = 0)
 {
@@ -1040,12 +1060,12 @@ static void q_launch(tahoe_forest *f, const tahoe_qgroup &g, float *sums, const 
     const int lds = REG ? (int)qreg_lds_for(K, NWALK, RING, CODE8) : (int)qring_lds_for(f, NWALK, LDSX);
     const uint32_t *leaf_orig = f->leaf_orig + (size_t)g.tree_lo * f->n_leaf;
     if (leaf_out)
-        hipLaunchKernelGGL((qring_kernel<NWALK, true, LDSX, NARROW, EXCH, K, REG, RING, SPLIT, BATCH, CODE8>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, g.top,
+        hipLaunchKernelGGL((qring_kernel<NWALK, true, LDSX, NARROW, EXCH, K, REG, RING, SPLIT, BATCH, CODE8, DEP>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, g.top,
                            g.blocks, g.qinner, leaf_orig, sums, leaf_out, rows, f->p.num_cols, g.num_trees, f->depth,
                            q->top_levels, q->top_stride, q->chunk_flags, f->error_flag, sums_in, g.tree_lo, f->p.num_trees, cshift, leafbuf, leaf_stride,
                            slices, row_begin);
     else
-        hipLaunchKernelGGL((qring_kernel<NWALK, false, LDSX, NARROW, EXCH, K, REG, RING, SPLIT, BATCH, CODE8>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, g.top,
+        hipLaunchKernelGGL((qring_kernel<NWALK, false, LDSX, NARROW, EXCH, K, REG, RING, SPLIT, BATCH, CODE8, DEP>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, g.top,
                            g.blocks, g.qinner, leaf_orig, sums, leaf_out, rows, f->p.num_cols, g.num_trees, f->depth,
                            q->top_levels, q->top_stride, q->chunk_flags, f->error_flag, sums_in, g.tree_lo, f->p.num_trees, cshift, leafbuf, leaf_stride,
                            slices, row_begin);
@@ -1137,18 +1157,18 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
                     q_launch<15, true, true, false, 2, true, kQRing, true>(f, g, sums, sums_in, leaf_out, rows, stream, cshift, slices);
                 else if (code8) {
                     if (rows3 > 0)
-                        q_launch<kReg8Walkers, true, true, false, 6, true, kReg8Ring, false, kReg8Batch, true>(f, g, sums, sums_in, leaf_out, rows3, stream, cshift);
+                        q_launch<kReg8Walkers, true, true, false, 6, true, kReg8Ring, false, kReg8Batch, true, kReg8Dep>(f, g, sums, sums_in, leaf_out, rows3, stream, cshift);
                     if (chains == 3)
-                        q_launch<kReg8Walkers, true, true, false, 6, true, kReg8Ring, false, kReg8Batch, true>(f, g, sums, sums_in, leaf_out, rows, stream, cshift, 1,
+                        q_launch<kReg8Walkers, true, true, false, 6, true, kReg8Ring, false, kReg8Batch, true, kReg8Dep>(f, g, sums, sums_in, leaf_out, rows, stream, cshift, 1,
                                                                                                          rows3);
                     else
                         q_launch<15, true, true, false, 2, true, kQRing, false, kQBatch, true>(f, g, sums, sums_in, leaf_out, rows, stream, cshift, 1, rows3);
                 }
                 else if (q->reg) {
                     if (rows3 > 0)
-                        q_launch<kReg3Walkers, true, true, false, 3, true, kReg3Ring>(f, g, sums, sums_in, leaf_out, rows3, stream, cshift);
+                        q_launch<kReg3Walkers, true, true, false, 3, true, kReg3Ring, false, kReg3Batch, false, kReg3Dep>(f, g, sums, sums_in, leaf_out, rows3, stream, cshift);
                     if (chains == 3)
-                        q_launch<kReg3Walkers, true, true, false, 3, true, kReg3Ring>(f, g, sums, sums_in, leaf_out, rows, stream, cshift, 1,
+                        q_launch<kReg3Walkers, true, true, false, 3, true, kReg3Ring, false, kReg3Batch, false, kReg3Dep>(f, g, sums, sums_in, leaf_out, rows, stream, cshift, 1,
                                                                                       rows3);
                     else
                         q_launch<15, true, true, false, 2, true>(f, g, sums, sums_in, leaf_out, rows, stream, cshift, 1, rows3);

@@ -106,6 +106,18 @@ inline long long qreg_lds_for(int k, int nwalk, int ring, bool code8 = false)
 #define TAHOE_Q8_BATCH 2
 #endif
 constexpr int kReg8Walkers = TAHOE_Q8_WALKERS, kReg8Ring = TAHOE_Q8_RING, kReg8Batch = TAHOE_Q8_BATCH;
+// top walk of the 384-row u8 tile / of the 192-row u16 tile: 1 = only the chosen child is read, after the compare (4 VALU + 2 LDS
+// per chain-level, two dependent LDS round trips), 0 = both children beside the feature read (5 VALU + 2 LDS, one round trip).
+// Measured (profiles/r04/tune_dep.txt): KR3's u8 walk 2.799 -> 2.731 ms, K3's u16 walk 3.469 -> 3.418 ms: on for both (round 2
+// measured "no faster" on the 128-row tile; with three / six chains per lane the second round trip hides behind the other chains)
+#ifndef TAHOE_Q8_DEP
+#define TAHOE_Q8_DEP 1
+#endif
+#ifndef TAHOE_R3_DEP
+#define TAHOE_R3_DEP 1
+#endif
+constexpr bool kReg8Dep = TAHOE_Q8_DEP != 0, kReg3Dep = TAHOE_R3_DEP != 0;
+constexpr int kReg3Batch = kReg3Ring >= 2 * kQBatch ? kQBatch : kReg3Ring / 2;  // consumer batch of the 192-row tile (the kernel's default rule)
 #ifndef TAHOE_Q8_COST
 #define TAHOE_Q8_COST 218  // time of a 384-row u8 tile in percent of a 128-row u8 tile: KR3, 983,040 rows, 10 waves of 384-row tiles 2.665 ms
                            // against 30 waves of 128-row tiles 3.672 ms (profiles/r04/q8_cost.txt)

@@ -630,7 +630,8 @@ def test_quantiser_on_skewed_thresholds(env, monkeypatch, form):
 
 
 @pytest.mark.parametrize("T,D,C,R", [(120, 8, 18, 10_000),    # K1-like: memset + quantise + walk (tree slices + ordered sum) + transform
-                                     (200, 7, 2048, 5_000)])  # wide rows, the row-streaming form: its leaf-value workspace is reserved
+                                     (200, 7, 2048, 5_000),   # wide rows, the row-streaming form: its leaf-value workspace is reserved
+                                     (40, 8, 64, 60_000)])    # few thresholds per feature, a large batch: u8 codes, 384-row tiles + remainder
 def test_predict_is_capturable_in_a_hip_graph(env, T, D, C, R):
     """A predict on a reserved handle is a fixed sequence of stream operations (a memset, the quantise and walk
     kernels, the output transform): no allocation, no synchronisation.  It can therefore be captured into a
@@ -641,6 +642,8 @@ def test_predict_is_capturable_in_a_hip_graph(env, T, D, C, R):
     f = ta.Forest(nodes, T, D, C, missing=MISSING, output=ta.OUT_AVG | ta.OUT_SIGMOID, global_bias=0.1)
     if C > 512:
         assert f.info().stream_slots > 0 and f.get_strategy(R) == ta.STRATEGY_TILERING
+    if R > 50_000:
+        assert f.kernel_form(R) == "qring_region8"
     f.reserve(R)
     x = torch.empty((R, C), dtype=torch.float32, device="cuda")
     out = torch.zeros(R, dtype=torch.float32, device="cuda")
