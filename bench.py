@@ -127,8 +127,9 @@ def physical_ceilings(prof, walk_ms, quant_ms, rows, cols):
 # ---- the one honest fraction <= 1 the walk has: against the ceiling of the LDS-resident walk itself ----
 def lds_walk_ceiling(walk_ms, rows, trees, depth, num_cus, clock_ghz):
     """node visits per second of the walk kernel against what tools/ubench_qwalk.hip measures for the LDS-resident part of
-    the same walk alone (14 walker waves x 3 chains, 64-row regions, child pairs by ds_read_b64, no global memory): 7 vector
-    instructions (5 VALU + 2 LDS) per 64-row level, one vector instruction per CU and cycle.  The unit is a "wave-level":
+    the same walk alone (14 walker waves x 3 chains, 64-row regions, no global memory; the faster of its two level forms:
+    both children by ds_read_b64 + select = 5 VALU + 2 LDS, or the chosen child after the compare = 4 + 2, the form the
+    192- and 384-row tiles run): 6 vector instructions per 64-row level at best, one vector instruction per CU and cycle.  The unit is a "wave-level":
     one level of the walk for the 64 rows of one wave-chain.  Both times are wall times of whole kernels divided by the
     wave-levels per CU they contain, so the device clock cancels in `frac`."""
     wave_levels_per_cu = (rows / 64.0) * trees * depth / max(num_cus, 1)
@@ -136,7 +137,8 @@ def lds_walk_ceiling(walk_ms, rows, trees, depth, num_cus, clock_ghz):
     out = {"unit": "ns per wave-level (64 rows x one tree level) per CU", "kernel": round(ns_kernel, 4),
            "kernel_clk_at_device_clock": round(ns_kernel * clock_ghz, 3),
            "node_visits_per_s": round(rows * trees * depth / (walk_ms * 1e-3), 1),
-           "seven_instruction_floor_clk": 7.0, "frac_of_seven_instruction_floor": round(7.0 / (ns_kernel * clock_ghz), 4)}
+           "instruction_floor_clk": 6.0, "frac_of_instruction_floor": round(6.0 / (ns_kernel * clock_ghz), 4),
+           "instruction_floor_means": "4 VALU + 2 LDS per chain-level, one vector instruction per CU and cycle at the device clock"}
     exe = os.path.join(ROOT, "tools", "ubench_qwalk")
     ub, source = None, None
     if os.path.exists(exe):  # live, on this device, as a child process (its own HIP context)
@@ -150,8 +152,8 @@ def lds_walk_ceiling(walk_ms, rows, trees, depth, num_cus, clock_ghz):
         except (OSError, ValueError, subprocess.SubprocessError):
             ub = None
     if ub is None:  # the committed run of the same binary (2.4 GHz assumed in its clk figure)
-        ub = {"ns_per_wave_level_per_cu": 7.71 / 2.4, "nw": 14, "k": 3}
-        source = "profiles/r02/ubench_qwalk.txt (NW 14 K 3 colb 128 pair unrolled: 7.71 clk at 2.4 GHz); live run unavailable"
+        ub = {"ns_per_wave_level_per_cu": 7.55 / 2.4, "nw": 14, "k": 3}
+        source = "profiles/r04/bench_default_line.json (tools/ubench_qwalk --kernel-shape: 7.55 clk at 2.4 GHz); live run unavailable"
     out.update({"ubench": round(ub["ns_per_wave_level_per_cu"], 4), "ubench_shape": f"{ub.get('nw')} walker waves x {ub.get('k')} chains",
                 "ubench_source": source, "frac": round(ub["ns_per_wave_level_per_cu"] / ns_kernel, 4),
                 "frac_means": "time the LDS-resident walk alone needs per wave-level (micro-benchmark, no tops staged, no bottom blocks, "

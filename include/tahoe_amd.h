@@ -308,7 +308,10 @@ enum {
     TAHOE_FORM_SPARSE_ROWTILE = 15,       /* sparse_kernel with the 64-row float32 tile */
     TAHOE_FORM_SPARSE_TOP = 16,           /* sparse_top_kernel */
     TAHOE_FORM_SPARSE_QRING = 17,         /* sparse_q_kernel */
-    TAHOE_FORM_QRING_REGION8 = 18         /* qring8_kernel: 8-bit rank codes (<= 254 thresholds per feature), 384-row tiles */
+    TAHOE_FORM_QRING_REGION8 = 18,        /* qring_kernel on 8-bit rank codes (<= 254 thresholds per feature): 384-row tiles of three
+                                             128-row regions, six chains per lane (<= 128 features: 15 walkers, ring of 24) */
+    TAHOE_FORM_QRING_REGION6 = 19         /* qring_kernel on u16 codes, num_cols <= 128: 384-row tiles of six 64-row regions at a
+                                             16-KiB stride, six chains per lane */
 };
 int tahoe_forest_get_kernel_form(const tahoe_forest *f, size_t rows);
 const char *tahoe_kernel_form_name(int form);

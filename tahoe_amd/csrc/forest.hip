@@ -1331,7 +1331,7 @@ const char *tahoe_kernel_form_name(int form)
     static const char *const names[] = {"none", "direct", "rowtile", "tileblock", "tilering_tile", "tilering_wide_tile",
                                         "tilering_wide_stream", "qring_region3", "qring_region2", "qring_region_mixed",
                                         "qring_split", "qring_columns", "qring_wide", "qring_gx", "sparse_direct",
-                                        "sparse_rowtile", "sparse_top", "sparse_qring", "qring_region8"};
+                                        "sparse_rowtile", "sparse_top", "sparse_qring", "qring_region8", "qring_region6"};
     return form >= 0 && form < (int)(sizeof(names) / sizeof(names[0])) ? names[form] : "?";
 }
 
@@ -1370,7 +1370,7 @@ tahoe_status tahoe_forest_get_info(const tahoe_forest *f, tahoe_forest_info *inf
     info->stream_slots = widef_stream_slots(f);
     info->stream_levels = widef_stream_levels(f);
     info->stream_key_ties = widef_stream_tie_estimate(f);
-    info->qring_tile_rows = info->qring_walkers == 0 ? 0 : qwide_rows(f) ? qwide_rows(f) : qring_code8(f) ? 384 : qring_regions(f) ? 192 : qring_lds_tile(f) ? 128 : 0;
+    info->qring_tile_rows = info->qring_walkers == 0 ? 0 : qwide_rows(f) ? qwide_rows(f) : (qring_code8(f) || qring_six16(f)) ? 384 : qring_regions(f) ? 192 : qring_lds_tile(f) ? 128 : 0;
     info->relayout = f->relayout ? 1 : 0;
     info->relayout_swaps = f->relayout_swaps;
     return TAHOE_OK;

@@ -151,6 +151,7 @@ int qwide_rows(const tahoe_forest *f);   // rows per tile of the wide-row form; 
 int qwide_chains(const tahoe_forest *f); // ... and the trees a lane walks at once (1 or 3)
 bool qring_lds_tile(const tahoe_forest *f);
 bool qring_regions(const tahoe_forest *f);  // region form: tiles of 192 (or 128) rows as 64-row regions
+bool qring_six16(const tahoe_forest *f);    // ... <= 128 features: 16-KiB region stride, 384-row tiles also on u16 codes
 bool qring_code8(const tahoe_forest *f);    // ... on u8 codes (<= 254 thresholds per feature): tiles of 384 rows as 128-row regions
 int qring_groups(const tahoe_forest *f);  // tree groups with separate quantisation (1 for most forests)
 int qring_form(const tahoe_forest *f, size_t rows);  // TAHOE_FORM_* of the launch for a batch of `rows` rows

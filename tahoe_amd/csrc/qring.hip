@@ -71,8 +71,12 @@ namespace tahoe {
 // sequential float32 sum, where the reference's cub::DeviceSegmentedReduce adds per-block partial sums in another order.
 // CODE8 (region form on u8 codes, qring_internal.h): the tile is K / 2 regions of 128 rows, chain k = half k & 1 of region k >> 1;
 // the loop is the same instruction for instruction except that the feature code is a ds_read_u8.
+// REGB = LDS stride of a region: 32 KiB (num_cols <= 256), or 16 KiB for forests of <= 128 features (a region is cols x 128 bytes;
+// fid < 128 leaves bit 14 of the v_bfi field clear) -- six 64-row regions of u16 codes then fit where three did (384-row tiles for
+// narrow forests with any number of thresholds), and six chains of u8 codes leave room for 15 walkers and a ring of 24.
 template <int NWALK, bool WRITE_LEAF, bool LDSX, bool NARROW = false, bool EXCH = false, int K = 2, bool REG = false, int RING = kQRing,
-          bool SPLIT = false, int BATCH = (RING >= 2 * kQBatch ? kQBatch : RING / 2), bool CODE8 = false, bool DEP = false>
+          bool SPLIT = false, int BATCH = (RING >= 2 * kQBatch ? kQBatch : RING / 2), bool CODE8 = false, bool DEP = false,
+          int REGB = kRegBytes>
 __global__ void __launch_bounds__((NWALK + 1) * 64)
     qring_kernel(const uint16_t *__restrict__ xq, const uint32_t *__restrict__ top, const uint4 *__restrict__ blocks,
                  const uint32_t *__restrict__ qinner, const uint32_t *__restrict__ leaf_orig, float *sums,
@@ -88,8 +92,10 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
     static_assert(!REG || (LDSX && NARROW && !EXCH), "regions are a form of the NARROW LDS tile");
     static_assert(BATCH >= 1 && RING >= 2 * BATCH, "ring too small");
     static_assert(!CODE8 || (REG && K % 2 == 0 && !SPLIT), "u8 codes: whole 128-row regions, no tree slices");
+    static_assert(REGB == kRegBytes || (REG && REGB == kRegBytes / 2), "region stride: 32 KiB, or 16 KiB for <= 128 features");
     constexpr uint32_t MISSC = CODE8 ? kCodeMissing8 : kCodeMissing;
-    constexpr int NREG = CODE8 ? K / 2 : K;  // 32-KiB regions of the tile
+    constexpr int NREG = CODE8 ? K / 2 : K;  // regions of the tile
+    constexpr int FB = REGB == kRegBytes ? 8 : 7;  // fid bits of the LDS address (q_xread)
     constexpr int TR = 64 * K;             // rows per tile
     constexpr int CS = REG ? 7 : 8;        // log2 of a feature column's bytes
     constexpr int NT = (NWALK + 1) * 64;
@@ -104,7 +110,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
     const int slice = SPLIT ? (int)(blockIdx.x % (unsigned)slices) : 0;
     const int t_begin = SPLIT ? (int)((long long)num_trees * slice / slices) : 0;        // this workgroup's trees
     const int t_end = SPLIT ? (int)((long long)num_trees * (slice + 1) / slices) : num_trees;
-    unsigned char *slots = smem + (REG ? (size_t)NREG * kRegBytes : LDSX ? (size_t)cols * TR * sizeof(uint16_t) : 0);
+    unsigned char *slots = smem + (REG ? (size_t)NREG * REGB : LDSX ? (size_t)cols * TR * sizeof(uint16_t) : 0);
     const unsigned char *gx = reinterpret_cast<const unsigned char *>(xq + (size_t)tile_id * ((size_t)cols * TR));
     float *ring_vals = reinterpret_cast<float *>(slots + (size_t)NWALK * slot_bytes);
     uint32_t *ring_ready = reinterpret_cast<uint32_t *>(ring_vals + RING * TR);
@@ -124,7 +130,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
         const size_t first_region = CODE8 ? row0 >> 7 : row0 >> 6;
         for (int k = 0; k < NREG; ++k) {
             const uint4 *src = reinterpret_cast<const uint4 *>(xq + (first_region + (size_t)k) * ((size_t)cols * kRegRows));
-            uint4 *dst = reinterpret_cast<uint4 *>(smem + (size_t)k * kRegBytes);
+            uint4 *dst = reinterpret_cast<uint4 *>(smem + (size_t)k * REGB);
             for (int e = tid; e < n16; e += NT) dst[e] = src[e];
         }
     } else if (LDSX) {
@@ -218,8 +224,8 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
         uint32_t pos[K];  // byte position of this lane's row inside a 256-byte feature column, per chain
     #pragma unroll
         for (int k = 0; k < K; ++k)  // low 32 bits of a generic LDS pointer = the LDS byte address
-            pos[k] = CODE8 ? (uint32_t)((k >> 1) * kRegBytes) + (uint32_t)qreg8_pos((k & 1) * 64 + lane)
-                     : REG ? (uint32_t)(k * kRegBytes) + 2u * (uint32_t)qreg_pos(lane)
+            pos[k] = CODE8 ? (uint32_t)((k >> 1) * REGB) + (uint32_t)qreg8_pos((k & 1) * 64 + lane)
+                     : REG ? (uint32_t)(k * REGB) + 2u * (uint32_t)qreg_pos(lane)
                            : (LDSX ? (uint32_t)reinterpret_cast<uintptr_t>(tile) : 0u) + 2u * (uint32_t)qrow_pos(k * 64 + lane);
         const size_t n_inner = ((size_t)1 << depth) - 1;
         const uint32_t n_blocks = 1u << (depth - 2);
@@ -231,9 +237,9 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
             for (int k = 0; k < K; ++k) {
                 // two dependent steps (the kernel is VALU-bound: this is ~half the instructions of evaluating
                 // both second-level nodes)
-                const bool c0 = q_go_right<MS, NARROW, EXCH, MISSC>(q_xread<LDSX, NARROW, CS, CODE8>(gx, na[k].x, pos[k]), na[k].x);
+                const bool c0 = q_go_right<MS, NARROW, EXCH, MISSC>(q_xread<LDSX, NARROW, CS, CODE8, FB>(gx, na[k].x, pos[k]), na[k].x);
                 const uint32_t n1 = c0 ? na[k].z : na[k].y;
-                const bool c1 = q_go_right<MS, NARROW, EXCH, MISSC>(q_xread<LDSX, NARROW, CS, CODE8>(gx, n1, pos[k]), n1);
+                const bool c1 = q_go_right<MS, NARROW, EXCH, MISSC>(q_xread<LDSX, NARROW, CS, CODE8, FB>(gx, n1, pos[k]), n1);
                 const uint32_t lo = c0 ? nb[k].z : nb[k].x, hi = c0 ? nb[k].w : nb[k].y;
                 v[k] = __uint_as_float(c1 ? hi : lo);
                 if (WRITE_LEAF) {
@@ -290,7 +296,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                     for (int l = 0; l < top_levels - 1; ++l) {
                         uint32_t xc[K];
     #pragma unroll
-                        for (int k = 0; k < K; ++k) xc[k] = q_xread<LDSX, NARROW, CS, CODE8>(gx, node[k], pos[k]);
+                        for (int k = 0; k < K; ++k) xc[k] = q_xread<LDSX, NARROW, CS, CODE8, FB>(gx, node[k], pos[k]);
     #pragma unroll
                         for (int k = 0; k < K; ++k) {
                             i[k] = q_descend(i[k], q_right_mask<MS, NARROW, EXCH, MISSC>(xc[k], node[k]));
@@ -306,7 +312,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                     const uint2 pr0 = *reinterpret_cast<const uint2 *>(&slot[2]);
                     uint32_t xc0[K];
     #pragma unroll
-                    for (int k = 0; k < K; ++k) xc0[k] = q_xread<LDSX, NARROW, CS, CODE8>(gx, node[k], pos[k]);
+                    for (int k = 0; k < K; ++k) xc0[k] = q_xread<LDSX, NARROW, CS, CODE8, FB>(gx, node[k], pos[k]);
     #pragma unroll
                     for (int k = 0; k < K; ++k) {
                         const uint64_t cm = q_right_mask<MS, NARROW, EXCH, MISSC>(xc0[k], node[k]);
@@ -320,7 +326,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                     uint2 pr[K];
     #pragma unroll
                     for (int k = 0; k < K; ++k) {
-                        xc[k] = q_xread<LDSX, NARROW, CS, CODE8>(gx, node[k], pos[k]);
+                        xc[k] = q_xread<LDSX, NARROW, CS, CODE8, FB>(gx, node[k], pos[k]);
                         pr[k] = *reinterpret_cast<const uint2 *>(&slot[2 * i[k]]);  // children 2i, 2i+1
                     }
     #pragma unroll
@@ -333,7 +339,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                 }
     #pragma unroll
                 for (int k = 0; k < K; ++k) {
-                    const uint32_t xc = q_xread<LDSX, NARROW, CS, CODE8>(gx, node[k], pos[k]);
+                    const uint32_t xc = q_xread<LDSX, NARROW, CS, CODE8, FB>(gx, node[k], pos[k]);
                     i[k] = q_descend(i[k], q_right_mask<MS, NARROW, EXCH, MISSC>(xc, node[k]));
                 }
             }
@@ -345,7 +351,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                     const uint32_t *tree = qinner + (size_t)t * n_inner;
                     for (int l = top_levels; l < depth - 2; ++l) {
                         const uint32_t n = tree[idx];
-                        const uint32_t xc = q_xread<LDSX, NARROW, CS, CODE8>(gx, n, pos[k]);
+                        const uint32_t xc = q_xread<LDSX, NARROW, CS, CODE8, FB>(gx, n, pos[k]);
                         idx = 2u * idx + 1u + (q_go_right<MS, NARROW, EXCH, MISSC>(xc, n) ? 1u : 0u);
                     }
                 }
@@ -627,14 +633,24 @@ __global__ void __launch_bounds__(16 * 64)
 
 // ------------------------------------------------------------------------------------------------
 // Second step of the SPLIT form: per row, the leaf values of the group's trees in tree order, continuing sums_in.
-__global__ void __launch_bounds__(256) ordered_sum_kernel(const float *__restrict__ leafbuf, size_t leaf_stride, int num_trees,
-                                                          const float *sums_in, float *sums, size_t rows)
+// (Round 4: 64-thread workgroups -- a 10 k-row batch spreads over 157 CUs instead of 40 -- and 32 loads in flight per thread: the
+// kernel is a chain of dependent global-memory round trips, K1: 34 -> ~10 us.)
+constexpr int kOrderedSumThreads = 64;
+__global__ void __launch_bounds__(kOrderedSumThreads) ordered_sum_kernel(const float *__restrict__ leafbuf, size_t leaf_stride, int num_trees,
+                                                                         const float *sums_in, float *sums, size_t rows)
 {
-    const size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t row = (size_t)blockIdx.x * kOrderedSumThreads + threadIdx.x;
     if (row >= rows) return;
     float sum = sums_in ? sums_in[row] : 0.0f;
     int t = 0;
-    for (; t + 8 <= num_trees; t += 8) {  // eight loads in flight, eight adds in order
+    for (; t + 32 <= num_trees; t += 32) {  // 32 loads in flight, 32 adds in tree order
+        float v[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) v[j] = leafbuf[(size_t)(t + j) * leaf_stride + row];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) sum += v[j];
+    }
+    for (; t + 8 <= num_trees; t += 8) {
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = leafbuf[(size_t)(t + j) * leaf_stride + row];
@@ -731,7 +747,12 @@ static hipError_t q_allow(long long lds)
                           (const void *)&qring_kernel<kReg8Walkers, false, true, true, false, 6, true, kReg8Ring, false, kReg8Batch, true, kReg8Dep>,
                           (const void *)&qring_kernel<kReg8Walkers, true, true, true, false, 6, true, kReg8Ring, false, kReg8Batch, true, kReg8Dep>,
                           (const void *)&qring_kernel<15, false, true, true, false, 2, true, kQRing, false, kQBatch, true>,
-                          (const void *)&qring_kernel<15, true, true, true, false, 2, true, kQRing, false, kQBatch, true>})
+                          (const void *)&qring_kernel<15, true, true, true, false, 2, true, kQRing, false, kQBatch, true>,
+                          // <= 128 features: six 16-KiB regions of u16 codes; three 16-KiB regions of u8 codes, 15 walkers, ring of 24
+                          (const void *)&qring_kernel<kReg8Walkers, false, true, true, false, 6, true, kReg8Ring, false, kReg8Batch, false, kReg8Dep, kRegBytes / 2>,
+                          (const void *)&qring_kernel<kReg8Walkers, true, true, true, false, 6, true, kReg8Ring, false, kReg8Batch, false, kReg8Dep, kRegBytes / 2>,
+                          (const void *)&qring_kernel<15, false, true, true, false, 6, true, kQRing, false, kQBatch, true, kReg8Dep, kRegBytes / 2>,
+                          (const void *)&qring_kernel<15, true, true, true, false, 6, true, kQRing, false, kQBatch, true, kReg8Dep, kRegBytes / 2>})
         if ((e = allow_max_lds(k, (int)lds)) != hipSuccess) return e;
     return hipSuccess;
 }
@@ -927,6 +948,9 @@ tahoe_status qring_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner,
         for (const tahoe_qgroup &g : q->groups) most = std::max(most, g.max_count);
         const char *e8 = getenv("TAHOE_QRING_CODE8");  // experiments: 0 keeps u16 codes
         q->code8 = q->reg && most <= kQMaxTable8 && qreg_lds_for(6, kReg8Walkers, kReg8Ring, true) <= f->lds_limit && !(e8 && atoi(e8) == 0);
+        const char *e6 = getenv("TAHOE_QRING_NARROW128");  // experiments: 0 keeps the 32-KiB region stride for forests of <= 128 features
+        q->narrow128 = q->reg && cols <= 128 && qreg_lds_for(6, kReg8Walkers, kReg8Ring, false, kRegBytes / 2) <= f->lds_limit &&
+                       qreg_lds_for(6, 15, kQRing, true, kRegBytes / 2) <= f->lds_limit && !(e6 && atoi(e6) == 0);
     }
     // kernels that need more than 64 KiB of dynamic LDS
     hipError_t e;
@@ -964,6 +988,7 @@ void qring_destroy(tahoe_forest *f)
 int qring_groups(const tahoe_forest *f) { return f->q ? (int)f->q->groups.size() : 0; }
 bool qring_regions(const tahoe_forest *f) { return f->q && f->q->reg; }
 bool qring_code8(const tahoe_forest *f) { return f->q && f->q->code8; }
+bool qring_six16(const tahoe_forest *f) { return f->q && f->q->reg && f->q->narrow128; }
 
 // The quantised copy of the batch lives in a grow-only workspace owned by the handle.
 static int q_slices(const tahoe_forest *f, size_t rows, int *most_out);
@@ -975,7 +1000,8 @@ tahoe_status qring_reserve(tahoe_forest *f, size_t rows)
     if (!q) return TAHOE_OK;  // no quantised form on this handle
     size_t tiles = (rows + kQRows - 1) / kQRows;
     // region form: a walk tile reads two or three whole 64-row regions -> room for the last tile to read past the batch
-    if (q->reg) tiles = ((rows + kRegRows - 1) / kRegRows + 2 + 1) / 2;
+    // (six-region tiles of narrow forests: up to five regions past the last row)
+    if (q->reg) tiles = ((rows + kRegRows - 1) / kRegRows + (q->narrow128 ? 5 : 2) + 1) / 2;
     if (tiles * kQRows > q->xq_rows) {
         if (q->xq) {
             TAHOE_HIP_TRY(hipDeviceSynchronize());  // a previous launch may still read the old buffer
@@ -1048,7 +1074,7 @@ static tahoe_status qring_reserve_leafbuf(tahoe_forest *f, size_t rows, int tree
 }
 
 template <int NWALK, bool LDSX = true, bool NARROW = false, bool EXCH = false, int K = 2, bool REG = false, int RING = kQRing,
-          bool SPLIT = false, int BATCH = (RING >= 2 * kQBatch ? kQBatch : RING / 2), bool CODE8 = false, bool DEP = false>
+          bool SPLIT = false, int BATCH = (RING >= 2 * kQBatch ? kQBatch : RING / 2), bool CODE8 = false, bool DEP = false, int REGB = kRegBytes>
 static void q_launch(tahoe_forest *f, const tahoe_qgroup &g, float *sums, const float *sums_in, uint32_t *leaf_out,
                      size_t rows, hipStream_t stream, int cshift, int slices = 1, size_t row_begin = 0)
 {
@@ -1057,20 +1083,20 @@ static void q_launch(tahoe_forest *f, const tahoe_qgroup &g, float *sums, const 
     if (grid == 0) return;
     float *leafbuf = SPLIT ? q->leafbuf : nullptr;
     const size_t leaf_stride = SPLIT ? q->leaf_stride : 0;
-    const int lds = REG ? (int)qreg_lds_for(K, NWALK, RING, CODE8) : (int)qring_lds_for(f, NWALK, LDSX);
+    const int lds = REG ? (int)qreg_lds_for(K, NWALK, RING, CODE8, REGB) : (int)qring_lds_for(f, NWALK, LDSX);
     const uint32_t *leaf_orig = f->leaf_orig + (size_t)g.tree_lo * f->n_leaf;
     if (leaf_out)
-        hipLaunchKernelGGL((qring_kernel<NWALK, true, LDSX, NARROW, EXCH, K, REG, RING, SPLIT, BATCH, CODE8, DEP>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, g.top,
+        hipLaunchKernelGGL((qring_kernel<NWALK, true, LDSX, NARROW, EXCH, K, REG, RING, SPLIT, BATCH, CODE8, DEP, REGB>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, g.top,
                            g.blocks, g.qinner, leaf_orig, sums, leaf_out, rows, f->p.num_cols, g.num_trees, f->depth,
                            q->top_levels, q->top_stride, q->chunk_flags, f->error_flag, sums_in, g.tree_lo, f->p.num_trees, cshift, leafbuf, leaf_stride,
                            slices, row_begin);
     else
-        hipLaunchKernelGGL((qring_kernel<NWALK, false, LDSX, NARROW, EXCH, K, REG, RING, SPLIT, BATCH, CODE8, DEP>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, g.top,
+        hipLaunchKernelGGL((qring_kernel<NWALK, false, LDSX, NARROW, EXCH, K, REG, RING, SPLIT, BATCH, CODE8, DEP, REGB>), dim3(grid), dim3((NWALK + 1) * 64), lds, stream, q->xq, g.top,
                            g.blocks, g.qinner, leaf_orig, sums, leaf_out, rows, f->p.num_cols, g.num_trees, f->depth,
                            q->top_levels, q->top_stride, q->chunk_flags, f->error_flag, sums_in, g.tree_lo, f->p.num_trees, cshift, leafbuf, leaf_stride,
                            slices, row_begin);
     if (SPLIT && sums)
-        hipLaunchKernelGGL(ordered_sum_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, leafbuf, leaf_stride, g.num_trees,
+        hipLaunchKernelGGL(ordered_sum_kernel, dim3((unsigned)((rows + kOrderedSumThreads - 1) / kOrderedSumThreads)), dim3(kOrderedSumThreads), 0, stream, leafbuf, leaf_stride, g.num_trees,
                            sums_in, sums, rows);
 }
 
@@ -1121,7 +1147,8 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
     int most = 1;
     const int slices = q_slices(f, rows, &most);  // small batches of the region form: tree slices per tile (SPLIT)
     const bool code8 = q->code8 && slices <= 1;   // u8 codes: 384-row tiles for whole waves, 128-row tiles for the remainder
-    if (code8)
+    const bool six16 = !code8 && q->reg && q->narrow128 && slices <= 1;  // u16 codes, <= 128 features: six 16-KiB regions, the same plan
+    if (code8 || six16)
         qreg_plan(rows, f->num_cus, f->knob_qring_chains, &rows3, &chains, kReg8Cost, 384);
     else if (q->reg)
         qreg_plan(rows, f->num_cus, f->knob_qring_chains, &rows3, &chains);  // TAHOE_QRING_CHAINS = 2 / 3 forces one form
@@ -1155,6 +1182,14 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
             case 15:
                 if (q->reg && slices > 1)
                     q_launch<15, true, true, false, 2, true, kQRing, true>(f, g, sums, sums_in, leaf_out, rows, stream, cshift, slices);
+                else if (code8 && q->narrow128) {  // u8 codes, <= 128 features: three 16-KiB regions, 15 walkers, ring of 24
+                    if (rows3 > 0)
+                        q_launch<15, true, true, false, 6, true, kQRing, false, kQBatch, true, kReg8Dep, kRegBytes / 2>(f, g, sums, sums_in, leaf_out, rows3, stream, cshift);
+                    if (chains == 3)
+                        q_launch<15, true, true, false, 6, true, kQRing, false, kQBatch, true, kReg8Dep, kRegBytes / 2>(f, g, sums, sums_in, leaf_out, rows, stream, cshift, 1, rows3);
+                    else
+                        q_launch<15, true, true, false, 2, true, kQRing, false, kQBatch, true>(f, g, sums, sums_in, leaf_out, rows, stream, cshift, 1, rows3);
+                }
                 else if (code8) {
                     if (rows3 > 0)
                         q_launch<kReg8Walkers, true, true, false, 6, true, kReg8Ring, false, kReg8Batch, true, kReg8Dep>(f, g, sums, sums_in, leaf_out, rows3, stream, cshift);
@@ -1163,6 +1198,15 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
                                                                                                          rows3);
                     else
                         q_launch<15, true, true, false, 2, true, kQRing, false, kQBatch, true>(f, g, sums, sums_in, leaf_out, rows, stream, cshift, 1, rows3);
+                }
+                else if (six16) {  // u16 codes, <= 128 features: six 16-KiB regions = 384-row tiles, the u8 tile's walkers and ring
+                    if (rows3 > 0)
+                        q_launch<kReg8Walkers, true, true, false, 6, true, kReg8Ring, false, kReg8Batch, false, kReg8Dep, kRegBytes / 2>(f, g, sums, sums_in, leaf_out, rows3, stream, cshift);
+                    if (chains == 3)
+                        q_launch<kReg8Walkers, true, true, false, 6, true, kReg8Ring, false, kReg8Batch, false, kReg8Dep, kRegBytes / 2>(f, g, sums, sums_in, leaf_out, rows, stream, cshift, 1,
+                                                                                                                        rows3);
+                    else
+                        q_launch<15, true, true, false, 2, true>(f, g, sums, sums_in, leaf_out, rows, stream, cshift, 1, rows3);
                 }
                 else if (q->reg) {
                     if (rows3 > 0)
@@ -1203,6 +1247,7 @@ int qring_form(const tahoe_forest *f, size_t rows)
     size_t rows3 = 0;
     int chains = 2;
     if (q->code8) return TAHOE_FORM_QRING_REGION8;
+    if (q->narrow128) return TAHOE_FORM_QRING_REGION6;
     qreg_plan(rows, f->num_cus, f->knob_qring_chains, &rows3, &chains);
     if (rows3 > 0 && chains == 2) return TAHOE_FORM_QRING_REGION_MIXED;
     return chains == 3 ? TAHOE_FORM_QRING_REGION3 : TAHOE_FORM_QRING_REGION2;

@@ -44,6 +44,8 @@ struct tahoe_qstate {
     bool narrow = false;          // node words in the NARROW layout (num_cols <= 256, 15 walkers, LDS tile)
     bool reg = false;             // ... in its region form: fid << 7, tiles of two or three 64-row regions (qring.hip)
     bool sparse = false;          // the handle is a sparse forest: tables, workspace and region tiles only (sparse.hip walks)
+    bool narrow128 = false;       // region form, num_cols <= 128: regions at a 16-KiB stride -- six chains of u16 codes (384-row tiles), or
+                                  // six chains of u8 codes with 15 walkers and a ring of 24
     bool code8 = false;           // region form with every table <= 254 entries: large batches are quantised to u8 codes and walked
                                   // in 384-row tiles (six chains per lane)
     int wide_rt = 0;              // rows per tile of the wide-row form (qwide_kernel), fixed at create; 0 = not used
@@ -89,9 +91,9 @@ constexpr int kReg3Walkers = TAHOE_R3_WALKERS;
 constexpr int kReg3Ring = TAHOE_R3_RING;
 constexpr int kQMaxTable = 32767;
 // LDS of the region form: K regions of 32 KiB, walker slots, ring
-inline long long qreg_lds_for(int k, int nwalk, int ring, bool code8 = false)
+inline long long qreg_lds_for(int k, int nwalk, int ring, bool code8 = false, int regb = kRegBytes)
 {
-    return (long long)(code8 ? k / 2 : k) * kRegBytes + (long long)nwalk * kQSlotBytes + (long long)ring * k * kRegRows * 4 + (ring + 1) * 4LL;
+    return (long long)(code8 ? k / 2 : k) * regb + (long long)nwalk * kQSlotBytes + (long long)ring * k * kRegRows * 4 + (ring + 1) * 4LL;
 }
 // u8 form: six chains (384-row tiles of three 128-row regions) for whole waves of workgroups, two chains (one region) for
 // the remainder; walkers / ring / consumer batch of the 384-row tile: 14 / 5 / 2 (96 KiB + 14 x 4 KiB + 5 x 1.5 KiB = 163,352 B); KR3
@@ -262,7 +264,9 @@ __device__ __forceinline__ uint32_t q_descend(uint32_t i, uint64_t right_mask)
 // tile's base, posb = byte position inside a column.
 typedef const uint16_t __attribute__((address_space(3))) *lds_u16_ptr;
 typedef const uint8_t __attribute__((address_space(3))) *lds_u8_ptr;
-template <bool LDSX, bool NARROW, int CSHIFT = 8, bool U8 = false>
+// FB = bits of the fid field the address takes from the node word: 8, or 7 when the regions stand at a 16-KiB stride (num_cols <= 128:
+// bit 14 then belongs to the region base in posb, not to the fid).
+template <bool LDSX, bool NARROW, int CSHIFT = 8, bool U8 = false, int FB = 8>
 __device__ __forceinline__ uint32_t q_xread(const unsigned char *gx, uint32_t node, uint32_t posb)
 {
     static_assert(!NARROW || CSHIFT == 8 || CSHIFT == 7, "the NARROW layouts have 256- or 128-byte feature columns");
@@ -271,7 +275,7 @@ __device__ __forceinline__ uint32_t q_xread(const unsigned char *gx, uint32_t no
         // The tile starts at LDS address 0 (checked at kernel entry).  CSHIFT = 8: posb < 256, address = node[15:8] : posb[7:0].
         // CSHIFT = 7 (64-row regions at multiples of 32 KiB): posb = region base + slot (< 128), address takes node[14:7].
         uint32_t addr;
-        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(addr) : "s"(0xFFu << (CSHIFT == 7 ? 7 : 8)), "v"(node), "v"(posb));
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(addr) : "s"(((1u << FB) - 1u) << (CSHIFT == 7 ? 7 : 8)), "v"(node), "v"(posb));
         if (U8) return *reinterpret_cast<lds_u8_ptr>(addr);  // 128-row regions of u8 codes: ds_read_u8
         return *reinterpret_cast<lds_u16_ptr>(addr);
     }

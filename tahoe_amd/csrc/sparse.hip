@@ -300,6 +300,10 @@ __global__ void __launch_bounds__(NW * 64) sparse_top_kernel(const uint2 *__rest
 // bit-identical to a sequential CPU sum.  Tree groups (a feature with more than 32767 distinct thresholds) chain their
 // sums like the dense form.
 constexpr int kSQLevels = 9;
+#ifndef TAHOE_SQ_DEP
+#define TAHOE_SQ_DEP 0  // 1: the top walk reads only the chosen child (make SQDEP=1; K5 measured in profiles/r04/tune_dep.txt)
+#endif
+constexpr bool kSparseQDep = TAHOE_SQ_DEP != 0;
 template <int NWALK, bool WRITE_LEAF, int K, int RING>
 __global__ void __launch_bounds__((NWALK + 1) * 64)
     sparse_q_kernel(const uint16_t *__restrict__ xq, const uint32_t *__restrict__ qtop, const uint4 *__restrict__ qblocks,
@@ -484,33 +488,48 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                 i[k] = 1u;
                 node[k] = slot[1];
             }
-            {   // level 0: every chain is at the root -- one read of its child pair serves them all
-                const uint2 pr0 = *reinterpret_cast<const uint2 *>(&slot[2]);
-                uint32_t xc0[K];
+            if (kSparseQDep) {  // only the chosen child, read after the compare (4 VALU + 2 LDS per chain-level; qring.hip, DEP)
+                const uint32_t slot_a = (uint32_t)reinterpret_cast<uintptr_t>(slot);
+                for (int l = 0; l < kSQLevels - 1; ++l) {
+                    uint32_t xc[K];
 #pragma unroll
-                for (int k = 0; k < K; ++k) xc0[k] = q_xread<true, true, 7>(nullptr, node[k], pos[k]);
+                    for (int k = 0; k < K; ++k) xc[k] = q_xread<true, true, 7>(nullptr, node[k], pos[k]);
 #pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const uint64_t cm = q_right_mask<MS, true>(xc0[k], node[k]);
-                    i[k] = q_descend(i[k], cm);
-                    node[k] = __builtin_amdgcn_inverse_ballot_w64(cm) ? pr0.y : pr0.x;
+                    for (int k = 0; k < K; ++k) {
+                        i[k] = q_descend(i[k], q_right_mask<MS, true>(xc[k], node[k]));
+                        node[k] = *reinterpret_cast<const uint32_t __attribute__((address_space(3))) *>(slot_a + 4u * i[k]);
+                    }
+                    if (t_p >= 0 && (l == 3 || l == 6)) (void)deep_step();  // the previous tree, below its top
                 }
-            }
-            for (int l = 1; l < kSQLevels - 1; ++l) {  // both children come with one ds_read_b64 beside the code read
-                uint32_t xc[K];
-                uint2 pr[K];
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    xc[k] = q_xread<true, true, 7>(nullptr, node[k], pos[k]);
-                    pr[k] = *reinterpret_cast<const uint2 *>(&slot[2 * i[k]]);
+            } else {
+                {   // level 0: every chain is at the root -- one read of its child pair serves them all
+                    const uint2 pr0 = *reinterpret_cast<const uint2 *>(&slot[2]);
+                    uint32_t xc0[K];
+    #pragma unroll
+                    for (int k = 0; k < K; ++k) xc0[k] = q_xread<true, true, 7>(nullptr, node[k], pos[k]);
+    #pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const uint64_t cm = q_right_mask<MS, true>(xc0[k], node[k]);
+                        i[k] = q_descend(i[k], cm);
+                        node[k] = __builtin_amdgcn_inverse_ballot_w64(cm) ? pr0.y : pr0.x;
+                    }
                 }
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const uint64_t cm = q_right_mask<MS, true>(xc[k], node[k]);
-                    i[k] = q_descend(i[k], cm);
-                    node[k] = __builtin_amdgcn_inverse_ballot_w64(cm) ? pr[k].y : pr[k].x;
+                for (int l = 1; l < kSQLevels - 1; ++l) {  // both children come with one ds_read_b64 beside the code read
+                    uint32_t xc[K];
+                    uint2 pr[K];
+    #pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        xc[k] = q_xread<true, true, 7>(nullptr, node[k], pos[k]);
+                        pr[k] = *reinterpret_cast<const uint2 *>(&slot[2 * i[k]]);
+                    }
+    #pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const uint64_t cm = q_right_mask<MS, true>(xc[k], node[k]);
+                        i[k] = q_descend(i[k], cm);
+                        node[k] = __builtin_amdgcn_inverse_ballot_w64(cm) ? pr[k].y : pr[k].x;
+                    }
+                    if (t_p >= 0 && (l == 3 || l == 6)) (void)deep_step();  // the previous tree, below its top
                 }
-                if (t_p >= 0 && (l == 3 || l == 6)) (void)deep_step();  // the previous tree, below its top
             }
             uint32_t entry[K];  // what lies below the last level's branch: a leaf value, or the block where the walk goes on
             uint32_t act[K];    // 1: this chain's walk goes on below the top

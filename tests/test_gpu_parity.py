@@ -356,7 +356,8 @@ def test_batches_walked_as_waves_of_192_row_tiles_plus_a_128_row_remainder(env, 
     x = torch.from_numpy(data).cuda()
     forest = ta.Forest(nodes, T, D, C, missing=MISSING)
     forest.set_strategy(ta.STRATEGY_QRING)
-    assert forest.kernel_form(125_000) == ("qring_region8" if code8 == "1" else "qring_region_mixed")
+    # (64 features: regions at a 16-KiB stride -- six chains per lane on u16 codes too, the same 384 + 128 plan)
+    assert forest.kernel_form(125_000) == ("qring_region8" if code8 == "1" else "qring_region6")
     for rows in (110_000, 125_000, 147_457, 250_000, R):
         got = forest.predict_raw(x[:rows].contiguous())
         forest.check()
@@ -631,14 +632,15 @@ def test_quantiser_on_skewed_thresholds(env, monkeypatch, form):
 
 @pytest.mark.parametrize("T,D,C,R", [(120, 8, 18, 10_000),    # K1-like: memset + quantise + walk (tree slices + ordered sum) + transform
                                      (200, 7, 2048, 5_000),   # wide rows, the row-streaming form: its leaf-value workspace is reserved
-                                     (40, 8, 64, 60_000)])    # few thresholds per feature, a large batch: u8 codes, 384-row tiles + remainder
+                                     (150, 8, 64, 60_000)])   # histogram-style forest, a large batch: u8 codes, 384-row tiles + remainder
 def test_predict_is_capturable_in_a_hip_graph(env, T, D, C, R):
     """A predict on a reserved handle is a fixed sequence of stream operations (a memset, the quantise and walk
     kernels, the output transform): no allocation, no synchronisation.  It can therefore be captured into a
     hipGraph once and replayed -- the way a launch-bound caller (K1: 10 k rows, three launches per batch) removes
     the per-launch host cost.  Replays must give the oracle's bits, also after the input buffer changes."""
     ta, oracle, torch = env
-    nodes = ta.synth_forest(T, D, C, seed=91, leaf_prob=0.05)
+    nodes = (ta.synth_forest_hist(T, D, C, seed=91, feature_seed=3, max_bins=200, scale_decades=0.0) if R > 50_000 else
+             ta.synth_forest(T, D, C, seed=91, leaf_prob=0.05))
     f = ta.Forest(nodes, T, D, C, missing=MISSING, output=ta.OUT_AVG | ta.OUT_SIGMOID, global_bias=0.1)
     if C > 512:
         assert f.info().stream_slots > 0 and f.get_strategy(R) == ta.STRATEGY_TILERING
@@ -1035,9 +1037,9 @@ def test_qring_on_8bit_codes(env, monkeypatch, T, D, C, R, bins, missing_prob):
     f.set_strategy(ta.STRATEGY_QRING)
     want8 = most <= 254
     assert (f.kernel_form(R) == "qring_region8") == want8, (most, f.kernel_form(R))
-    assert f.info().qring_tile_rows == (384 if want8 else 192)
+    assert f.info().qring_tile_rows == (384 if (want8 or C <= 128) else 192)
     # small batches of forests with enough trees keep the u16 tree slices (a slice must still give every walker a few trees)
-    assert f.kernel_form(1000) == ("qring_split" if T >= 120 else "qring_region8" if want8 else "qring_region2")
+    assert f.kernel_form(1000) == ("qring_split" if T >= 120 else "qring_region8" if want8 else "qring_region6" if C <= 128 else "qring_region2")
     want, want_leaf = oracle.predict(nodes, T, D, data, MISSING, want_leaf=True, threads=8)
     x = torch.from_numpy(data).cuda()
     for _ in range(2):
@@ -1058,7 +1060,47 @@ def test_qring_on_8bit_codes(env, monkeypatch, T, D, C, R, bins, missing_prob):
     monkeypatch.setenv("TAHOE_QRING_CODE8", "0")
     g = ta.Forest(nodes, T, D, C, missing=MISSING)
     g.set_strategy(ta.STRATEGY_QRING)
-    assert g.kernel_form(R) != "qring_region8"
+    assert g.kernel_form(R) in (("qring_region6",) if C <= 128 else ("qring_region_mixed", "qring_region3", "qring_region2"))
+    assert np.array_equal(bits(g.predict_raw(x).cpu().numpy()), bits(want))
+    g.check()
+    g.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,D,C,R,missing_prob", [
+    (300, 8, 18, 60_001, 0.01),    # SUSY-like width, random thresholds (~4 k per feature): u16 codes, six 16-KiB regions
+    (150, 10, 128, 45_000, 0.0),   # the widest forest of the form
+    (300, 8, 100, 30_000, 0.02),
+])
+def test_narrow_forests_walk_384_row_tiles_on_u16_codes(env, monkeypatch, T, D, C, R, missing_prob):
+    """num_cols <= 128: a 64-row region of u16 codes is at most 16 KiB, so six of them fit where three 32-KiB regions did -- 384
+    rows per staged top with any number of thresholds per feature (qring_kernel<..., K = 6, REGB = 16 KiB>).  Leaf indices, sums
+    and continued sums against the oracle; TAHOE_QRING_NARROW128=0 (the 192-row tiles) gives the same bits."""
+    ta, oracle, torch = env
+    monkeypatch.delenv("TAHOE_QRING_NARROW128", raising=False)
+    nodes = ta.synth_forest(T, D, C, seed=700 + T, leaf_prob=0.03)
+    data = ta.synth_data(R, C, seed=800 + T, missing_prob=missing_prob, missing=MISSING, nan_prob=missing_prob / 2)
+    f = ta.Forest(nodes, T, D, C, missing=MISSING)
+    f.set_strategy(ta.STRATEGY_QRING)
+    assert f.kernel_form(R) == "qring_region6" and f.info().qring_tile_rows == 384
+    want, want_leaf = oracle.predict(nodes, T, D, data, MISSING, want_leaf=True, threads=8)
+    x = torch.from_numpy(data).cuda()
+    for rows in (R, 384 * 256 + 5, 777):
+        rows = min(rows, R)
+        leaf, sums = f.predict_leaf_idx(x[:rows].contiguous())
+        raw = f.predict_raw(x[:rows].contiguous())
+        f.check()
+        assert np.array_equal(bits(leaf.cpu().numpy()), want_leaf[:rows]), rows
+        assert np.array_equal(bits(sums.cpu().numpy()), bits(want[:rows])) and np.array_equal(bits(raw.cpu().numpy()), bits(want[:rows])), rows
+    start = np.linspace(-1.0, 1.0, R).astype(np.float32)
+    acc = f.predict_accumulate(x, torch.from_numpy(start.copy()).cuda())
+    f.check()
+    assert np.array_equal(bits(acc.cpu().numpy()), bits(oracle.predict_continue(nodes, T, D, data, MISSING, start)))
+    f.close()
+    monkeypatch.setenv("TAHOE_QRING_NARROW128", "0")
+    g = ta.Forest(nodes, T, D, C, missing=MISSING)
+    g.set_strategy(ta.STRATEGY_QRING)
+    assert g.kernel_form(R) in ("qring_region_mixed", "qring_region3", "qring_region2") and g.info().qring_tile_rows == 192
     assert np.array_equal(bits(g.predict_raw(x).cpu().numpy()), bits(want))
     g.check()
     g.close()
