@@ -114,7 +114,8 @@ def physical_ceilings(prof, walk_ms, quant_ms, rows, cols):
             # FETCH_SIZE counts half of a wide coalesced stream (MI355X_MICROARCH.md, HBM): the quantised tiles are one
             tile_stream = rows * cols * 2
             ent["hbm_bytes_counters_corrected"] = int(fetch + write + tile_stream / 2)
-            ent["binds"] = "vector issue (VALU + LDS + VMEM instructions per SIMD) with the texture path close behind"
+            ent["binds"] = ("texture data path: per (tree, tile) a 4-KiB top staged from L2 (4 wave-loads) + one divergent 64-lane gather per chain "
+                            "and 16-byte piece of a bottom block, ~45 cycles each whatever the width; vector issue (VALU + LDS + VMEM per SIMD) behind it")
         else:
             moved = rows * cols * 4 + rows * cols * 2  # rows read once, codes written once
             ent["hbm_GBps_compulsory"] = round(moved / (ms * 1e-3) / 1e9, 1)

@@ -136,6 +136,10 @@ enum {
                                     waves of 192-row tiles + a remainder of 128-row tiles; small batches
                                     give every tile to several workgroups, each a slice of the trees, and
                                     an ordered-sum kernel adds the leaf values in tree order (SPLIT).
+                                    Forests whose features each see <= 254 thresholds (histogram-trained
+                                    models) are quantised to 8-bit ranks for batches of whole tiles: 384-row
+                                    tiles of three 128-row regions, six chains per lane; forests of <= 128
+                                    features walk 384-row tiles on 16-bit ranks too (regions at a 16-KiB stride).
                                     Wider rows: 128-row tiles, or 64- / 32- / 16-row tiles with several
                                     trees per wave.  Forests with more than 32767 distinct thresholds on a
                                     feature are walked in groups of consecutive trees with chained float32
