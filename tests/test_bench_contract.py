@@ -100,3 +100,30 @@ def test_committed_pmc_profile_belongs_to_these_kernel_sources():
         for key in ("vector_issue_busy", "valu_busy", "lds_busy", "texture_addr_busy", "hbm_frac_counters_raw"):
             assert 0.0 < phys[kern][key] <= 1.0, (kern, key, phys[kern][key])
     assert phys["quantise"]["hbm_frac_compulsory"] < 0.5  # the kernel furthest from its HBM roofline, said so
+
+
+def test_walk_ceiling_and_config_roofline_arithmetic():
+    """bench.py's host-side arithmetic without a GPU: the <= 1 fraction (here the live micro-benchmark cannot run, so the committed
+    figure serves and says so), the per-configuration byte model on a hand example, and the workloads of the `configs` legs."""
+    import sys
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    # 1 M rows x 1000 trees x 12 levels on 256 CUs in 3.4 ms: 1.2e10 visits = 732,421.875 wave-levels per CU
+    c = bench.lds_walk_ceiling(3.4, 1_000_000, 1000, 12, 256, 2.4)
+    assert abs(c["kernel"] - 3.4e6 / 732421.875) < 1e-3 and abs(c["node_visits_per_s"] - 1.2e10 / 3.4e-3) / c["node_visits_per_s"] < 1e-9
+    assert abs(c["frac"] - c["ubench"] / c["kernel"]) < 1e-3 and 0.0 < c["frac"] <= 1.0
+    assert abs(c["frac_of_instruction_floor"] - 6.0 / (c["kernel"] * 2.4)) < 1e-3
+    assert "live" in c["ubench_source"]  # either measured live, or the committed figure with "live run unavailable"
+    # byte model (SURVEY 8d): rows x (len x (node + 4) + trees x leaf + cols x 4 + 4); compulsory: rows x cols x 4 + nodes x node + rows x 4
+    r = bench.config_roofline(1.0, rows=10, cols=4, trees=3, len_sum_per_row=6.0, node_bytes=6, n_nodes=21, cfg="none")
+    assert r["algorithmic_bytes"] == 10 * (6 * 10 + 3 * 6 + 16 + 4) and r["compulsory_bytes"] == 10 * 16 + 21 * 6 + 40
+    assert r["counters"] is None and abs(r["frac"] - r["algorithmic_bytes"] / 1e-3 / 1e9 / 8000.0) < 1e-4
+    assert bench.dense_path_len_sum(__import__("numpy").array([[0, 2, 6], [1, 3, 14]])) == (0 + 1 + 2 + 1 + 2 + 3) / 2
+    import tahoe_amd as ta
+
+    kind, (nodes, T, D, C), data = bench.baseline_workload(ta, "K1", through_text_files=True)
+    assert kind == "dense" and (T, D, C) == (500, 8, 18) and data.shape == (10_000, 18) and nodes.size == T * 511
+    kind, (sn, tr, C5), _ = bench.baseline_workload(ta, "K5")
+    assert kind == "sparse" and tr.size == 2000 and C5 == 256 and 9_000_000 < sn.size < 10_500_000
