@@ -91,7 +91,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
     static_assert(REG || K == kQRows / 64, "the 128-slot column layout holds exactly two chains");
     static_assert(!REG || (LDSX && NARROW && !EXCH), "regions are a form of the NARROW LDS tile");
     static_assert(BATCH >= 1 && RING >= 2 * BATCH, "ring too small");
-    static_assert(!CODE8 || (REG && K % 2 == 0 && !SPLIT), "u8 codes: whole 128-row regions, no tree slices");
+    static_assert(!CODE8 || (REG && K % 2 == 0), "u8 codes: whole 128-row regions");
     static_assert(REGB == kRegBytes || (REG && REGB == kRegBytes / 2), "region stride: 32 KiB, or 16 KiB for <= 128 features");
     constexpr uint32_t MISSC = CODE8 ? kCodeMissing8 : kCodeMissing;
     constexpr int NREG = CODE8 ? K / 2 : K;  // regions of the tile
@@ -748,6 +748,8 @@ static hipError_t q_allow(long long lds)
                           (const void *)&qring_kernel<kReg8Walkers, true, true, true, false, 6, true, kReg8Ring, false, kReg8Batch, true, kReg8Dep>,
                           (const void *)&qring_kernel<15, false, true, true, false, 2, true, kQRing, false, kQBatch, true>,
                           (const void *)&qring_kernel<15, true, true, true, false, 2, true, kQRing, false, kQBatch, true>,
+                          (const void *)&qring_kernel<15, false, true, true, false, 2, true, kQRing, true, kQBatch, true>,
+                          (const void *)&qring_kernel<15, true, true, true, false, 2, true, kQRing, true, kQBatch, true>,
                           // <= 128 features: six 16-KiB regions of u16 codes; three 16-KiB regions of u8 codes, 15 walkers, ring of 24
                           (const void *)&qring_kernel<kReg8Walkers, false, true, true, false, 6, true, kReg8Ring, false, kReg8Batch, false, kReg8Dep, kRegBytes / 2>,
                           (const void *)&qring_kernel<kReg8Walkers, true, true, true, false, 6, true, kReg8Ring, false, kReg8Batch, false, kReg8Dep, kRegBytes / 2>,
@@ -797,6 +799,8 @@ static tahoe_status build_group(tahoe_forest *f, const std::vector<InnerNode> &h
             const auto &v = tab[fid];
             code = (uint32_t)(std::lower_bound(v.begin(), v.end(), n.thr) - v.begin()) + 1u;
         }
+        // u8 handles (every table <= 254 entries): M << 24 | code8 << 16 | fid << 7 | def_left, M = def_left ? 0xFF : 0 (q_right_mask)
+        if (q->code8) return ((dl ? 0xFFu : 0u) << 24) | ((code == 0xFFFFu ? 0xFFu : code) << 16) | (fid << 7) | dl;
         if (q->reg) return (code << 16) | (fid << 7) | dl;  // region form: the column offset fid * 128 is a bit field of the node
         return q->narrow ? (code << 16) | (fid << 8) | (ex << 7) | dl : code | (fid << 16) | (dl << 31);
     };
@@ -908,6 +912,10 @@ tahoe_status qring_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner,
         });
         const size_t most = *std::max_element(distinct.begin(), distinct.end());
         if (most > (size_t)kQMaxTable) G = (most + kQMaxTable - 1) / kQMaxTable;  // a group sees at most the forest's distinct count
+        // u8 codes (histogram-trained forests: <= 254 thresholds per feature): decided here, before the node words are encoded --
+        // such a handle has its own node encoding and only ever quantises to u8 (large batches, remainders and tree slices alike)
+        const char *e8 = getenv("TAHOE_QRING_CODE8");  // experiments: 0 keeps u16 codes
+        q->code8 = q->reg && most <= (size_t)kQMaxTable8 && qreg_lds_for(6, kReg8Walkers, kReg8Ring, true) <= f->lds_limit && !(e8 && atoi(e8) == 0);
         if (const char *k = getenv("TAHOE_QRING_GROUPS"))  // experiments: at least this many groups (K4: 8 groups of 1000 trees
             G = std::max(G, (size_t)std::max(atoi(k), 1));  // take the bucketed quantise kernel, 4 of 2000 the two-pass one)
     }
@@ -942,12 +950,7 @@ tahoe_status qring_build(tahoe_forest *f, const std::vector<InnerNode> &h_inner,
         }
         G = std::max(G + 1, (size_t)((double)G * worst / kQMaxTable + 0.999));
     }
-    // u8 codes (histogram-trained forests: <= 254 thresholds per feature in every group): region form only
-    {
-        int most = 0;
-        for (const tahoe_qgroup &g : q->groups) most = std::max(most, g.max_count);
-        const char *e8 = getenv("TAHOE_QRING_CODE8");  // experiments: 0 keeps u16 codes
-        q->code8 = q->reg && most <= kQMaxTable8 && qreg_lds_for(6, kReg8Walkers, kReg8Ring, true) <= f->lds_limit && !(e8 && atoi(e8) == 0);
+    {   // <= 128 features: regions at a 16-KiB LDS stride
         const char *e6 = getenv("TAHOE_QRING_NARROW128");  // experiments: 0 keeps the 32-KiB region stride for forests of <= 128 features
         q->narrow128 = q->reg && cols <= 128 && qreg_lds_for(6, kReg8Walkers, kReg8Ring, false, kRegBytes / 2) <= f->lds_limit &&
                        qreg_lds_for(6, 15, kQRing, true, kRegBytes / 2) <= f->lds_limit && !(e6 && atoi(e6) == 0);
@@ -1146,9 +1149,9 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
     int chains = 2;     // form of the remaining rows [rows3, rows)
     int most = 1;
     const int slices = q_slices(f, rows, &most);  // small batches of the region form: tree slices per tile (SPLIT)
-    const bool code8 = q->code8 && slices <= 1;   // u8 codes: 384-row tiles for whole waves, 128-row tiles for the remainder
+    const bool code8 = q->code8;                  // u8 codes: 384-row tiles for whole waves, 128-row tiles for the remainder and for tree slices
     const bool six16 = !code8 && q->reg && q->narrow128 && slices <= 1;  // u16 codes, <= 128 features: six 16-KiB regions, the same plan
-    if (code8 || six16)
+    if ((code8 && slices <= 1) || six16)
         qreg_plan(rows, f->num_cus, f->knob_qring_chains, &rows3, &chains, kReg8Cost, 384);
     else if (q->reg)
         qreg_plan(rows, f->num_cus, f->knob_qring_chains, &rows3, &chains);  // TAHOE_QRING_CHAINS = 2 / 3 forces one form
@@ -1180,7 +1183,9 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
         else
         switch (nwalk) {
             case 15:
-                if (q->reg && slices > 1)
+                if (q->reg && slices > 1 && code8)
+                    q_launch<15, true, true, false, 2, true, kQRing, true, kQBatch, true>(f, g, sums, sums_in, leaf_out, rows, stream, cshift, slices);
+                else if (q->reg && slices > 1)
                     q_launch<15, true, true, false, 2, true, kQRing, true>(f, g, sums, sums_in, leaf_out, rows, stream, cshift, slices);
                 else if (code8 && q->narrow128) {  // u8 codes, <= 128 features: three 16-KiB regions, 15 walkers, ring of 24
                     if (rows3 > 0)

@@ -231,10 +231,20 @@ template <bool MS, bool NARROW, bool EX = false, uint32_t MISSC = kCodeMissing>
 __device__ __forceinline__ uint64_t q_right_mask(uint32_t xc, uint32_t node)
 {
     static_assert(!EX || NARROW, "the exchange bit lives in the NARROW node word");
+    if (MISSC == kCodeMissing8) {
+        // u8 codes (handles built for them: q->code8): node = M << 24 | code8 << 16 | fid << 7 | def_left with M = def_left ? 0xFF : 0.
+        // A missing x has code 0xFF, >= every threshold code (a NaN threshold's 0xFF too), so `ge` alone sends it right; it must go
+        // LEFT exactly where def_left is set, i.e. where xc == M: right = ge & ~(xc == M) -- two SDWA byte compares and one s_andn2
+        // (the u16 rule takes three compares and three scalar operations).  xc == M can also hold for xc == 0 at a node without
+        // def_left: ge is false there anyway (codes start at 1; a padding node's code 0 has identical subtrees).
+        const uint64_t ge = __builtin_amdgcn_uicmp(xc, (node >> 16) & 0xFFu, 35 /* ICMP_UGE */);
+        if (!MS) return ge;
+        return ge & ~__builtin_amdgcn_uicmp(xc, node >> 24, 32 /* ICMP_EQ */);
+    }
     const uint64_t ge = __builtin_amdgcn_uicmp(xc, NARROW ? node >> 16 : node & 0xFFFFu, 35 /* ICMP_UGE */);
     uint64_t right = ge;
     if (MS) {
-        const uint64_t ms = __builtin_amdgcn_uicmp(xc, MISSC, 32 /* ICMP_EQ: the row's code says "missing" (0xFFFF; 0xFF for u8 codes) */);
+        const uint64_t ms = __builtin_amdgcn_uicmp(xc, MISSC, 32 /* ICMP_EQ: the row's code says "missing" (0xFFFF) */);
         const uint64_t ndl = NARROW ? __builtin_amdgcn_uicmp(node & 0x1u, 0u, 32 /* ICMP_EQ: def_left clear */)
                                     : __builtin_amdgcn_sicmp((int)node, -1, 38 /* ICMP_SGT: bit 31 (def_left) clear */);
         right = (ge & ~ms) | (ms & ndl);
