@@ -96,6 +96,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
     constexpr uint32_t MISSC = CODE8 ? kCodeMissing8 : kCodeMissing;
     constexpr int NREG = CODE8 ? K / 2 : K;  // regions of the tile
     constexpr int FB = REGB == kRegBytes ? 8 : 7;  // fid bits of the LDS address (q_xread)
+    constexpr int DLB = (REG && !CODE8) ? 15 : 0;  // def_left bit of the node word (q_right_mask)
     constexpr int TR = 64 * K;             // rows per tile
     constexpr int CS = REG ? 7 : 8;        // log2 of a feature column's bytes
     constexpr int NT = (NWALK + 1) * 64;
@@ -237,9 +238,9 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
             for (int k = 0; k < K; ++k) {
                 // two dependent steps (the kernel is VALU-bound: this is ~half the instructions of evaluating
                 // both second-level nodes)
-                const bool c0 = q_go_right<MS, NARROW, EXCH, MISSC>(q_xread<LDSX, NARROW, CS, CODE8, FB>(gx, na[k].x, pos[k]), na[k].x);
+                const bool c0 = q_go_right<MS, NARROW, EXCH, MISSC, DLB>(q_xread<LDSX, NARROW, CS, CODE8, FB>(gx, na[k].x, pos[k]), na[k].x);
                 const uint32_t n1 = c0 ? na[k].z : na[k].y;
-                const bool c1 = q_go_right<MS, NARROW, EXCH, MISSC>(q_xread<LDSX, NARROW, CS, CODE8, FB>(gx, n1, pos[k]), n1);
+                const bool c1 = q_go_right<MS, NARROW, EXCH, MISSC, DLB>(q_xread<LDSX, NARROW, CS, CODE8, FB>(gx, n1, pos[k]), n1);
                 const uint32_t lo = c0 ? nb[k].z : nb[k].x, hi = c0 ? nb[k].w : nb[k].y;
                 v[k] = __uint_as_float(c1 ? hi : lo);
                 if (WRITE_LEAF) {
@@ -299,7 +300,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                         for (int k = 0; k < K; ++k) xc[k] = q_xread<LDSX, NARROW, CS, CODE8, FB>(gx, node[k], pos[k]);
     #pragma unroll
                         for (int k = 0; k < K; ++k) {
-                            i[k] = q_descend(i[k], q_right_mask<MS, NARROW, EXCH, MISSC>(xc[k], node[k]));
+                            i[k] = q_descend(i[k], q_right_mask<MS, NARROW, EXCH, MISSC, DLB>(xc[k], node[k]));
                             node[k] = *reinterpret_cast<const uint32_t __attribute__((address_space(3))) *>(slot_a + 4u * i[k]);
                         }
                     }
@@ -315,7 +316,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                     for (int k = 0; k < K; ++k) xc0[k] = q_xread<LDSX, NARROW, CS, CODE8, FB>(gx, node[k], pos[k]);
     #pragma unroll
                     for (int k = 0; k < K; ++k) {
-                        const uint64_t cm = q_right_mask<MS, NARROW, EXCH, MISSC>(xc0[k], node[k]);
+                        const uint64_t cm = q_right_mask<MS, NARROW, EXCH, MISSC, DLB>(xc0[k], node[k]);
                         i[k] = q_descend(i[k], cm);
                         node[k] = __builtin_amdgcn_inverse_ballot_w64(cm) ? pr0.y : pr0.x;
                     }
@@ -331,7 +332,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                     }
     #pragma unroll
                     for (int k = 0; k < K; ++k) {
-                        const uint64_t cm = q_right_mask<MS, NARROW, EXCH, MISSC>(xc[k], node[k]);
+                        const uint64_t cm = q_right_mask<MS, NARROW, EXCH, MISSC, DLB>(xc[k], node[k]);
                         i[k] = q_descend(i[k], cm);
                         node[k] = __builtin_amdgcn_inverse_ballot_w64(cm) ? pr[k].y : pr[k].x;
                     }
@@ -340,7 +341,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
     #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     const uint32_t xc = q_xread<LDSX, NARROW, CS, CODE8, FB>(gx, node[k], pos[k]);
-                    i[k] = q_descend(i[k], q_right_mask<MS, NARROW, EXCH, MISSC>(xc, node[k]));
+                    i[k] = q_descend(i[k], q_right_mask<MS, NARROW, EXCH, MISSC, DLB>(xc, node[k]));
                 }
             }
             uint32_t bsel[K];
@@ -352,7 +353,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                     for (int l = top_levels; l < depth - 2; ++l) {
                         const uint32_t n = tree[idx];
                         const uint32_t xc = q_xread<LDSX, NARROW, CS, CODE8, FB>(gx, n, pos[k]);
-                        idx = 2u * idx + 1u + (q_go_right<MS, NARROW, EXCH, MISSC>(xc, n) ? 1u : 0u);
+                        idx = 2u * idx + 1u + (q_go_right<MS, NARROW, EXCH, MISSC, DLB>(xc, n) ? 1u : 0u);
                     }
                 }
                 bsel[k] = idx - first_block_node;
@@ -801,7 +802,8 @@ static tahoe_status build_group(tahoe_forest *f, const std::vector<InnerNode> &h
         }
         // u8 handles (every table <= 254 entries): M << 24 | code8 << 16 | fid << 7 | def_left, M = def_left ? 0xFF : 0 (q_right_mask)
         if (q->code8) return ((dl ? 0xFFu : 0u) << 24) | ((code == 0xFFFFu ? 0xFFu : code) << 16) | (fid << 7) | dl;
-        if (q->reg) return (code << 16) | (fid << 7) | dl;  // region form: the column offset fid * 128 is a bit field of the node
+        // region form: the column offset fid * 128 is a bit field of the node; def_left in bit 15, the sign of the low half
+        if (q->reg) return (code << 16) | (dl << 15) | (fid << 7);
         return q->narrow ? (code << 16) | (fid << 8) | (ex << 7) | dl : code | (fid << 16) | (dl << 31);
     };
     const size_t Tg = hi - lo;

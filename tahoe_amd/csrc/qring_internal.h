@@ -227,9 +227,13 @@ inline hipError_t q_upload(T **dst, const T *src, size_t count, size_t *total)
 // (fid * 256) is a bit field of the node word and one v_bfi forms the read address (q_xread).
 // EX (NARROW only; probability-guided re-layout): bit 7 of the node word marks a node whose children are stored swapped;
 // the condition is inverted there.  One more v_cmp (the sign of byte 0) and one s_xor per step.
-template <bool MS, bool NARROW, bool EX = false, uint32_t MISSC = kCodeMissing>
+// DLB = bit of the node word that holds def_left in the NARROW layouts: 0 (128-slot columns, u8 words) or 15 (region form on u16
+// codes, dense and sparse: "def_left clear" is then one signed compare of the sign-extended low half -- v_cmp_ge_i32_sdwa
+// sext(WORD_0) -- instead of v_and + v_cmp; the walk with the missing rule takes three compares per level, not four operations).
+template <bool MS, bool NARROW, bool EX = false, uint32_t MISSC = kCodeMissing, int DLB = 0>
 __device__ __forceinline__ uint64_t q_right_mask(uint32_t xc, uint32_t node)
 {
+    static_assert(DLB == 0 || (DLB == 15 && NARROW && !EX && MISSC == kCodeMissing), "bit 15: the u16 region word only");
     static_assert(!EX || NARROW, "the exchange bit lives in the NARROW node word");
     if (MISSC == kCodeMissing8) {
         // u8 codes (handles built for them: q->code8): node = M << 24 | code8 << 16 | fid << 7 | def_left with M = def_left ? 0xFF : 0.
@@ -245,17 +249,18 @@ __device__ __forceinline__ uint64_t q_right_mask(uint32_t xc, uint32_t node)
     uint64_t right = ge;
     if (MS) {
         const uint64_t ms = __builtin_amdgcn_uicmp(xc, MISSC, 32 /* ICMP_EQ: the row's code says "missing" (0xFFFF) */);
-        const uint64_t ndl = NARROW ? __builtin_amdgcn_uicmp(node & 0x1u, 0u, 32 /* ICMP_EQ: def_left clear */)
-                                    : __builtin_amdgcn_sicmp((int)node, -1, 38 /* ICMP_SGT: bit 31 (def_left) clear */);
-        right = (ge & ~ms) | (ms & ndl);
+        const uint64_t ndl = DLB == 15 ? __builtin_amdgcn_sicmp((int)(int16_t)(node & 0xFFFFu), 0, 39 /* ICMP_SGE: bit 15 (def_left) clear */)
+                             : NARROW  ? __builtin_amdgcn_uicmp(node & 0x1u, 0u, 32 /* ICMP_EQ: def_left clear */)
+                                       : __builtin_amdgcn_sicmp((int)node, -1, 38 /* ICMP_SGT: bit 31 (def_left) clear */);
+        right = ge & ~(ms & ~ndl);  // = (ge & ~ms) | (ms & ndl): a missing code (the largest) is >= every threshold code, so ms implies ge
     }
     if (EX) right ^= __builtin_amdgcn_sicmp((int)(int8_t)(node & 0xFFu), 0, 40 /* ICMP_SLT: bit 7 (exchange) set */);
     return right;
 }
-template <bool MS, bool NARROW, bool EX = false, uint32_t MISSC = kCodeMissing>
+template <bool MS, bool NARROW, bool EX = false, uint32_t MISSC = kCodeMissing, int DLB = 0>
 __device__ __forceinline__ bool q_go_right(uint32_t xc, uint32_t node)
 {
-    return __builtin_amdgcn_inverse_ballot_w64(q_right_mask<MS, NARROW, EX, MISSC>(xc, node));
+    return __builtin_amdgcn_inverse_ballot_w64(q_right_mask<MS, NARROW, EX, MISSC, DLB>(xc, node));
 }
 // i <- 2i + (lane's bit of mask): one v_addc with the mask as carry-in
 __device__ __forceinline__ uint32_t q_descend(uint32_t i, uint64_t right_mask)

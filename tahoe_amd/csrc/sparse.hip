@@ -39,8 +39,8 @@ struct tahoe_sstate {
     int32_t *ctrees = nullptr;  // [T + 1] offsets into cnodes (even)
     uint32_t *corig = nullptr;  // compact position -> index relative to the root in the caller's numbering
     // quantised form for sparse_q_kernel (null when num_cols > 256 or a single tree exceeds the code range); the threshold
-    // tables, the code workspace and the tree groups live in f->q (qring_internal.h).  Node word = code << 16 | fid << 7 |
-    // def_left (bits 6..1 free for flags).
+    // tables, the code workspace and the tree groups live in f->q (qring_internal.h).  Node word = code << 16 | def_left << 15 | fid << 7
+    // (bits 6..0 free for flags).
     // qtop [T][1024] u32: the first kSQLevels levels of every tree as a complete heap (early leaves padded down), the form the
     //   walker slots hold: entries 1..511 node words (1-based heap positions, children of i = 2i, 2i+1; bits 1 / 2 of a
     //   last-level word: the left / right child continues below the top), entries 512..1023 what lies below each last-level
@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(NW * 64) sparse_top_kernel(const uint2 *__rest
 // [fid][64] u16 (32 KiB each), K = 3 chains per lane (192 rows) walk a tree whose top is staged once into the walker's
 // 4 KiB LDS slot -- three independent dependent-read chains per walker wave where the float32 tile kernel has one.
 // Top of a tree = its first kSQLevels = 9 levels as a COMPLETE heap (an early leaf is padded down to the last level: both
-// children of a padding node carry the value), 4-byte node words code << 16 | fid << 7 | def_left at 1-based positions, so
+// children of a padding node carry the value), 4-byte node words code << 16 | def_left << 15 | fid << 7 at 1-based positions, so
 // the children of i are the aligned pair (2i, 2i+1): one ds_read_b64 beside the code read, one v_addc per level, no
 // per-lane "am I at a leaf yet" state -- the irregular shape costs nothing inside the top.  Entries 512..1023 hold what
 // lies below each last-level branch: a leaf value (most lanes end here) or, flagged in the last-level node word, the
@@ -434,9 +434,9 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                 // per chain, and only a chain that still has a lane under way (the long tails are one or two lanes of one
                 // chain); a finished lane of such a chain computes on stale registers and keeps its value
                 if (__ballot(act_p[k] != 0u) == 0ull) continue;
-                const bool c0 = q_go_right<MS, true>(q_xread<true, true, 7>(nullptr, a_p[k].x, pos[k]), a_p[k].x);
+                const bool c0 = q_go_right<MS, true, false, kCodeMissing, 15>(q_xread<true, true, 7>(nullptr, a_p[k].x, pos[k]), a_p[k].x);
                 const uint32_t n1 = c0 ? a_p[k].z : a_p[k].y;
-                const bool c1 = q_go_right<MS, true>(q_xread<true, true, 7>(nullptr, n1, pos[k]), n1);
+                const bool c1 = q_go_right<MS, true, false, kCodeMissing, 15>(q_xread<true, true, 7>(nullptr, n1, pos[k]), n1);
                 const uint32_t lo = c0 ? b_p[k].z : b_p[k].x, hi = c0 ? b_p[k].w : b_p[k].y;
                 const uint32_t j = (c0 ? 2u : 0u) + (c1 ? 1u : 0u);
                 const bool on = act_p[k] != 0u;
@@ -496,7 +496,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                     for (int k = 0; k < K; ++k) xc[k] = q_xread<true, true, 7>(nullptr, node[k], pos[k]);
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
-                        i[k] = q_descend(i[k], q_right_mask<MS, true>(xc[k], node[k]));
+                        i[k] = q_descend(i[k], q_right_mask<MS, true, false, kCodeMissing, 15>(xc[k], node[k]));
                         node[k] = *reinterpret_cast<const uint32_t __attribute__((address_space(3))) *>(slot_a + 4u * i[k]);
                     }
                     if (t_p >= 0 && (l == 3 || l == 6)) (void)deep_step();  // the previous tree, below its top
@@ -509,7 +509,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                     for (int k = 0; k < K; ++k) xc0[k] = q_xread<true, true, 7>(nullptr, node[k], pos[k]);
     #pragma unroll
                     for (int k = 0; k < K; ++k) {
-                        const uint64_t cm = q_right_mask<MS, true>(xc0[k], node[k]);
+                        const uint64_t cm = q_right_mask<MS, true, false, kCodeMissing, 15>(xc0[k], node[k]);
                         i[k] = q_descend(i[k], cm);
                         node[k] = __builtin_amdgcn_inverse_ballot_w64(cm) ? pr0.y : pr0.x;
                     }
@@ -524,7 +524,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
                     }
     #pragma unroll
                     for (int k = 0; k < K; ++k) {
-                        const uint64_t cm = q_right_mask<MS, true>(xc[k], node[k]);
+                        const uint64_t cm = q_right_mask<MS, true, false, kCodeMissing, 15>(xc[k], node[k]);
                         i[k] = q_descend(i[k], cm);
                         node[k] = __builtin_amdgcn_inverse_ballot_w64(cm) ? pr[k].y : pr[k].x;
                     }
@@ -536,7 +536,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const uint32_t xc = q_xread<true, true, 7>(nullptr, node[k], pos[k]);
-                const uint64_t cm = q_right_mask<MS, true>(xc, node[k]);
+                const uint64_t cm = q_right_mask<MS, true, false, kCodeMissing, 15>(xc, node[k]);
                 i[k] = q_descend(i[k], cm);  // NBOT .. 2 NBOT - 1
                 act[k] = (__builtin_amdgcn_inverse_ballot_w64(cm) ? node[k] >> 2 : node[k] >> 1) & 1u;
             }
@@ -806,7 +806,7 @@ static tahoe_status sparse_q_build(tahoe_forest *f, const std::vector<uint2> &cn
                         const auto &v = tab[fid];
                         code = (uint32_t)(std::lower_bound(v.begin(), v.end(), thr) - v.begin()) + 1u;
                     }
-                    qn[i] = make_uint2((code << 16) | (fid << 7) | dl, c.y >> 16);
+                    qn[i] = make_uint2((code << 16) | (dl << 15) | (fid << 7), c.y >> 16);  // def_left in bit 15 (q_right_mask, DLB)
                 }
             });
             tahoe_qgroup g;
