@@ -254,7 +254,7 @@ __global__ void __launch_bounds__((NWALK + 1) * 64)
     #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     const size_t row = row0 + k * 64 + lane;
-                    if (row < rows) leafbuf[(size_t)t * leaf_stride + row] = v[k];
+                    if (row < rows) leafbuf[(size_t)t * leaf_stride + (row - row_begin)] = v[k];  // (rows of this launch: [row_begin, rows))
                 }
                 return;
             }
@@ -638,27 +638,29 @@ __global__ void __launch_bounds__(16 * 64)
 // kernel is a chain of dependent global-memory round trips, K1: 34 -> ~10 us.)
 constexpr int kOrderedSumThreads = 64;
 __global__ void __launch_bounds__(kOrderedSumThreads) ordered_sum_kernel(const float *__restrict__ leafbuf, size_t leaf_stride, int num_trees,
-                                                                         const float *sums_in, float *sums, size_t rows)
+                                                                         const float *sums_in, float *sums, size_t rows, size_t row_begin)
 {
-    const size_t row = (size_t)blockIdx.x * kOrderedSumThreads + threadIdx.x;
+    // rows [row_begin, rows) of the batch; leafbuf[tree][row - row_begin]
+    const size_t r = (size_t)blockIdx.x * kOrderedSumThreads + threadIdx.x;
+    const size_t row = row_begin + r;
     if (row >= rows) return;
     float sum = sums_in ? sums_in[row] : 0.0f;
     int t = 0;
     for (; t + 32 <= num_trees; t += 32) {  // 32 loads in flight, 32 adds in tree order
         float v[32];
 #pragma unroll
-        for (int j = 0; j < 32; ++j) v[j] = leafbuf[(size_t)(t + j) * leaf_stride + row];
+        for (int j = 0; j < 32; ++j) v[j] = leafbuf[(size_t)(t + j) * leaf_stride + r];
 #pragma unroll
         for (int j = 0; j < 32; ++j) sum += v[j];
     }
     for (; t + 8 <= num_trees; t += 8) {
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = leafbuf[(size_t)(t + j) * leaf_stride + row];
+        for (int j = 0; j < 8; ++j) v[j] = leafbuf[(size_t)(t + j) * leaf_stride + r];
 #pragma unroll
         for (int j = 0; j < 8; ++j) sum += v[j];
     }
-    for (; t < num_trees; ++t) sum += leafbuf[(size_t)t * leaf_stride + row];
+    for (; t < num_trees; ++t) sum += leafbuf[(size_t)t * leaf_stride + r];
     sums[row] = sum;
 }
 
@@ -1101,8 +1103,8 @@ static void q_launch(tahoe_forest *f, const tahoe_qgroup &g, float *sums, const 
                            q->top_levels, q->top_stride, q->chunk_flags, f->error_flag, sums_in, g.tree_lo, f->p.num_trees, cshift, leafbuf, leaf_stride,
                            slices, row_begin);
     if (SPLIT && sums)
-        hipLaunchKernelGGL(ordered_sum_kernel, dim3((unsigned)((rows + kOrderedSumThreads - 1) / kOrderedSumThreads)), dim3(kOrderedSumThreads), 0, stream, leafbuf, leaf_stride, g.num_trees,
-                           sums_in, sums, rows);
+        hipLaunchKernelGGL(ordered_sum_kernel, dim3((unsigned)((rows - row_begin + kOrderedSumThreads - 1) / kOrderedSumThreads)), dim3(kOrderedSumThreads), 0, stream,
+                           leafbuf, leaf_stride, g.num_trees, sums_in, sums, rows, row_begin);
 }
 
 template <int RT, int KG, int RB>
@@ -1154,14 +1156,25 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
     const bool code8 = q->code8;                  // u8 codes: 384-row tiles for whole waves, 128-row tiles for the remainder and for tree slices
     const bool six16 = !code8 && q->reg && q->narrow128 && slices <= 1;  // u16 codes, <= 128 features: six 16-KiB regions, the same plan
     if ((code8 && slices <= 1) || six16)
-        qreg_plan(rows, f->num_cus, f->knob_qring_chains, &rows3, &chains, kReg8Cost, 384);
-    else if (q->reg)
-        qreg_plan(rows, f->num_cus, f->knob_qring_chains, &rows3, &chains);  // TAHOE_QRING_CHAINS = 2 / 3 forces one form
+        qreg_plan(rows, f->num_cus, f->knob_qring_chains, &rows3, &chains, kReg8Cost, 384, f->knob_qring_slices == 1 ? 0 : most);
+    else if (q->reg)  // TAHOE_QRING_CHAINS = 2 / 3 forces one form, TAHOE_QRING_SLICES = 1 keeps every remainder in plain tiles
+        qreg_plan(rows, f->num_cus, f->knob_qring_chains, &rows3, &chains, 133, 192, f->knob_qring_slices == 1 ? 0 : most);
     if (slices > 1) {
         const tahoe_status ls = qring_reserve_leafbuf(f, rows, most);  // no-op after tahoe_forest_reserve / a first predict
         if (ls != TAHOE_OK) return ls;
         chains = 2;
         rows3 = 0;
+    }
+    // A remainder of few 128-row tiles behind the whole waves of large tiles would leave most of the chip idle for a whole tile
+    // time (250 k rows of K3's forest: 5 waves of 192-row tiles + 34 tiles of 128): it is walked in tree slices too -- every
+    // remainder tile by rem_slices workgroups, then the ordered sum over those rows (bit-identical: the same sequential sum).
+    int rem_slices = 1;
+    if (q->reg && slices <= 1 && rows3 > 0 && chains == 2 && f->knob_qring_slices != 1) {
+        rem_slices = qreg_rem_slices(rows - rows3, f->num_cus, most);  // the planner priced the remainder with the same rule
+        if (rem_slices > 1) {
+            const tahoe_status ls = qring_reserve_leafbuf(f, rows - rows3, most);  // no-op after tahoe_forest_reserve / a first predict
+            if (ls != TAHOE_OK) return ls;
+        }
     }
     bool first = true;
     for (const tahoe_qgroup &g : q->groups) {  // stream order: quantise for the group, walk the group, next group
@@ -1194,6 +1207,8 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
                         q_launch<15, true, true, false, 6, true, kQRing, false, kQBatch, true, kReg8Dep, kRegBytes / 2>(f, g, sums, sums_in, leaf_out, rows3, stream, cshift);
                     if (chains == 3)
                         q_launch<15, true, true, false, 6, true, kQRing, false, kQBatch, true, kReg8Dep, kRegBytes / 2>(f, g, sums, sums_in, leaf_out, rows, stream, cshift, 1, rows3);
+                    else if (rem_slices > 1)
+                        q_launch<15, true, true, false, 2, true, kQRing, true, kQBatch, true>(f, g, sums, sums_in, leaf_out, rows, stream, cshift, rem_slices, rows3);
                     else
                         q_launch<15, true, true, false, 2, true, kQRing, false, kQBatch, true>(f, g, sums, sums_in, leaf_out, rows, stream, cshift, 1, rows3);
                 }
@@ -1203,6 +1218,8 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
                     if (chains == 3)
                         q_launch<kReg8Walkers, true, true, false, 6, true, kReg8Ring, false, kReg8Batch, true, kReg8Dep>(f, g, sums, sums_in, leaf_out, rows, stream, cshift, 1,
                                                                                                          rows3);
+                    else if (rem_slices > 1)
+                        q_launch<15, true, true, false, 2, true, kQRing, true, kQBatch, true>(f, g, sums, sums_in, leaf_out, rows, stream, cshift, rem_slices, rows3);
                     else
                         q_launch<15, true, true, false, 2, true, kQRing, false, kQBatch, true>(f, g, sums, sums_in, leaf_out, rows, stream, cshift, 1, rows3);
                 }
@@ -1212,6 +1229,8 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
                     if (chains == 3)
                         q_launch<kReg8Walkers, true, true, false, 6, true, kReg8Ring, false, kReg8Batch, false, kReg8Dep, kRegBytes / 2>(f, g, sums, sums_in, leaf_out, rows, stream, cshift, 1,
                                                                                                                         rows3);
+                    else if (rem_slices > 1)
+                        q_launch<15, true, true, false, 2, true, kQRing, true>(f, g, sums, sums_in, leaf_out, rows, stream, cshift, rem_slices, rows3);
                     else
                         q_launch<15, true, true, false, 2, true>(f, g, sums, sums_in, leaf_out, rows, stream, cshift, 1, rows3);
                 }
@@ -1221,6 +1240,8 @@ tahoe_status qring_launch(tahoe_forest *f, float *sums, uint32_t *leaf_out, cons
                     if (chains == 3)
                         q_launch<kReg3Walkers, true, true, false, 3, true, kReg3Ring, false, kReg3Batch, false, kReg3Dep>(f, g, sums, sums_in, leaf_out, rows, stream, cshift, 1,
                                                                                       rows3);
+                    else if (rem_slices > 1)
+                        q_launch<15, true, true, false, 2, true, kQRing, true>(f, g, sums, sums_in, leaf_out, rows, stream, cshift, rem_slices, rows3);
                     else
                         q_launch<15, true, true, false, 2, true>(f, g, sums, sums_in, leaf_out, rows, stream, cshift, 1, rows3);
                 }
@@ -1255,7 +1276,7 @@ int qring_form(const tahoe_forest *f, size_t rows)
     int chains = 2;
     if (q->code8) return TAHOE_FORM_QRING_REGION8;
     if (q->narrow128) return TAHOE_FORM_QRING_REGION6;
-    qreg_plan(rows, f->num_cus, f->knob_qring_chains, &rows3, &chains);
+    qreg_plan(rows, f->num_cus, f->knob_qring_chains, &rows3, &chains, 133, 192, f->knob_qring_slices == 1 ? 0 : most);
     if (rows3 > 0 && chains == 2) return TAHOE_FORM_QRING_REGION_MIXED;
     return chains == 3 ? TAHOE_FORM_QRING_REGION3 : TAHOE_FORM_QRING_REGION2;
 }

@@ -132,10 +132,21 @@ constexpr size_t kReg8Cost = TAHOE_Q8_COST;
 // 10 k rows: 79 tiles of 128).  Any cut is correct.  *rows3 = rows [0, rows3) in 192-row tiles (a multiple of 384),
 // *chains = form of the remaining rows [rows3, rows).  `force` = 2 / 3: one form for the whole batch.  cost3 = time of a
 // 192-row tile in percent of a 128-row tile (dense walk: 133; the sparse walk's three chains cost more: 161, sparse.hip).
-inline void qreg_plan(size_t rows, int num_cus, int force, size_t *rows3, int *chains, size_t cost3 = 133, size_t big = 192)
+// Tree slices of a remainder (dense region forms): when the 128-row tiles behind the whole waves are at most half the CUs, every
+// tile is given to `s` workgroups, each a slice of the trees, and an ordered-sum kernel adds the leaf values (qring_launch); the
+// remainder then costs ~100 / s + 35 (the second kernel and the leaf buffer; measured on K3: 250 k rows 35, 500 k rows 85 for s = 7 / 3) instead of 100.  `slice_trees` = trees of the largest
+// group (0: no slices -- sparse handles); a slice must keep >= 60 trees (4 per walker).
+inline int qreg_rem_slices(size_t rem_rows, int num_cus, int slice_trees)
 {
-    // (`big` = rows of the large tile: 192 for u16 codes; the u8 form plans 384-row tiles against 128-row ones with its own
-    // cost ratio and reads *chains == 3 as "the large tile")
+    if (rem_rows == 0 || slice_trees < 120) return 1;
+    const size_t tiles = (rem_rows + 127) / 128;
+    const int fit = (int)std::min<size_t>((size_t)std::max(num_cus, 1) / tiles, 8);
+    return std::max(1, std::min(fit, slice_trees / 60));
+}
+inline void qreg_plan(size_t rows, int num_cus, int force, size_t *rows3, int *chains, size_t cost3 = 133, size_t big = 192, int slice_trees = 0)
+{
+    // (`big` = rows of the large tile: 192 for u16 codes; the u8 form and narrow forests plan 384-row tiles against 128-row ones
+    // with their own cost ratio and read *chains == 3 as "the large tile")
     *rows3 = 0;
     *chains = 2;
     const size_t cus = (size_t)std::max(num_cus, 1);
@@ -147,7 +158,12 @@ inline void qreg_plan(size_t rows, int num_cus, int force, size_t *rows3, int *c
     size_t best = SIZE_MAX;
     for (size_t n = 0; n <= waves(rows, big); ++n) {
         const size_t r3 = std::min(rows, n * cus * big / 384 * 384), rem = rows - r3;
-        const size_t c2 = 100 * waves(rem, 128), c3 = cost3 * waves(rem, big);
+        size_t c2 = 100 * waves(rem, 128);
+        const size_t c3 = cost3 * waves(rem, big);
+        if (r3 > 0) {  // a small remainder in tree slices
+            const int s = qreg_rem_slices(rem, num_cus, slice_trees);
+            if (s > 1) c2 = std::min(c2, (size_t)(100 / s + 35));
+        }
         const size_t cost = cost3 * waves(r3, big) + std::min(c2, c3);
         if (cost < best) {
             best = cost;

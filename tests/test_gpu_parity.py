@@ -1104,3 +1104,46 @@ def test_narrow_forests_walk_384_row_tiles_on_u16_codes(env, monkeypatch, T, D, 
     assert np.array_equal(bits(g.predict_raw(x).cpu().numpy()), bits(want))
     g.check()
     g.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["u16_wide", "u16_narrow", "u8"])
+def test_small_remainder_behind_whole_waves_is_walked_in_tree_slices(env, monkeypatch, kind):
+    """A batch of one whole wave of large tiles + a few hundred rows: the remainder's few 128-row tiles are given to several
+    workgroups each (tree slices) and an ordered sum over those rows, so that it does not cost a whole tile time on a mostly idle
+    chip.  Same bits as the oracle (sums, continued sums, leaf indices) and as the plain remainder (TAHOE_QRING_SLICES=1)."""
+    ta, oracle, torch = env
+    monkeypatch.delenv("TAHOE_QRING_SLICES", raising=False)
+    T, D = 200, (7 if kind == "u8" else 9)  # (depth 9: > 254 thresholds per feature -> u16 codes)
+    if kind == "u8":
+        C = 200
+        nodes = ta.synth_forest_hist(T, D, C, seed=611, feature_seed=29, max_bins=200, scale_decades=2.0)
+    else:
+        C = 200 if kind == "u16_wide" else 64
+        nodes = ta.synth_forest(T, D, C, seed=612, leaf_prob=0.02)
+    f = ta.Forest(nodes, T, D, C, missing=MISSING)
+    f.set_strategy(ta.STRATEGY_QRING)
+    big = 192 if kind == "u16_wide" else 384
+    R = f.info().num_cus * big + 777
+    assert f.kernel_form(R) == {"u16_wide": "qring_region_mixed", "u16_narrow": "qring_region6", "u8": "qring_region8"}[kind]
+    data = (ta.synth_data_hist(R, C, seed=613, feature_seed=29, scale_decades=2.0, missing_prob=0.01, missing=MISSING) if kind == "u8" else
+            ta.synth_data(R, C, seed=613, missing_prob=0.01, missing=MISSING))
+    want, want_leaf = oracle.predict(nodes, T, D, data, MISSING, want_leaf=True, threads=8)
+    x = torch.from_numpy(data).cuda()
+    f.reserve(R)
+    leaf, sums = f.predict_leaf_idx(x)
+    raw = f.predict_raw(x)
+    f.check()
+    assert np.array_equal(bits(leaf.cpu().numpy()), want_leaf)
+    assert np.array_equal(bits(sums.cpu().numpy()), bits(want)) and np.array_equal(bits(raw.cpu().numpy()), bits(want))
+    start = np.linspace(-1.0, 1.0, R).astype(np.float32)
+    acc = f.predict_accumulate(x, torch.from_numpy(start.copy()).cuda())
+    f.check()
+    assert np.array_equal(bits(acc.cpu().numpy()), bits(oracle.predict_continue(nodes, T, D, data, MISSING, start)))
+    f.close()
+    monkeypatch.setenv("TAHOE_QRING_SLICES", "1")  # the remainder as plain 128-row tiles
+    g = ta.Forest(nodes, T, D, C, missing=MISSING)
+    g.set_strategy(ta.STRATEGY_QRING)
+    assert np.array_equal(bits(g.predict_raw(x).cpu().numpy()), bits(want))
+    g.check()
+    g.close()
