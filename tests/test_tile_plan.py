@@ -67,8 +67,8 @@ def test_known_plans_and_forced_forms(probe):
     # K3 on 256 CUs: 20 waves of 192-row tiles + 16,960 rows in 128-row tiles; one of 8 GPUs' share: 2 waves + 26,696 rows;
     # KR3 on u8 codes: 10 waves of 384-row tiles + the same remainder; forced forms leave the cut to the caller
     # with tree slices for small remainders (1000 trees): 250 k rows = 5 waves of 192-row tiles + 34 tiles of 128 in 7 slices each
-    # (without: 4 waves + 418 tiles of 128), 500 k rows = 10 waves + 67 tiles in 3 slices
+    # (without: 4 waves + 418 tiles of 128); 500 k rows: 9 waves + 451 plain tiles still price one unit below 10 waves + 67 tiles in 3 slices
     inp = ("1000000 256 0 133 192 0\n125000 256 0 133 192 0\n1000000 256 0 218 384 0\n125000 256 0 218 384 0\n1000000 256 2 133 192 0\n"
            "1000000 256 3 133 192 0\n250000 256 0 133 192 0\n250000 256 0 133 192 1000\n500000 256 0 133 192 1000\n1000000 256 0 133 192 1000\n")
     out = subprocess.run([probe], input=inp, capture_output=True, text=True, check=True).stdout.split()
-    assert out == ["983040", "2", "98304", "2", "983040", "2", "98304", "2", "0", "2", "0", "3", "196608", "2", "245760", "2", "491520", "2", "983040", "2"]
+    assert out == ["983040", "2", "98304", "2", "983040", "2", "98304", "2", "0", "2", "0", "3", "196608", "2", "245760", "2", "442368", "2", "983040", "2"]
