@@ -134,7 +134,7 @@ constexpr size_t kReg8Cost = TAHOE_Q8_COST;
 // 192-row tile in percent of a 128-row tile (dense walk: 133; the sparse walk's three chains cost more: 161, sparse.hip).
 // Tree slices of a remainder (dense region forms): when the 128-row tiles behind the whole waves are at most half the CUs, every
 // tile is given to `s` workgroups, each a slice of the trees, and an ordered-sum kernel adds the leaf values (qring_launch); the
-// remainder then costs ~100 / s + 35 (the second kernel and the leaf buffer; measured on K3: 250 k rows 35, 500 k rows 85 for s = 7 / 3) instead of 100.  `slice_trees` = trees of the largest
+// remainder then costs ~100 / s + 20 (the second kernel and the leaf buffer; measured on K3, profiles/r04/rem_slices.txt: 35 at s = 7, 52 at s = 3) instead of 100.  `slice_trees` = trees of the largest
 // group (0: no slices -- sparse handles); a slice must keep >= 60 trees (4 per walker).
 inline int qreg_rem_slices(size_t rem_rows, int num_cus, int slice_trees)
 {
@@ -162,7 +162,7 @@ inline void qreg_plan(size_t rows, int num_cus, int force, size_t *rows3, int *c
         const size_t c3 = cost3 * waves(rem, big);
         if (r3 > 0) {  // a small remainder in tree slices
             const int s = qreg_rem_slices(rem, num_cus, slice_trees);
-            if (s > 1) c2 = std::min(c2, (size_t)(100 / s + 35));
+            if (s > 1) c2 = std::min(c2, (size_t)(100 / s + 20));
         }
         const size_t cost = cost3 * waves(r3, big) + std::min(c2, c3);
         if (cost < best) {

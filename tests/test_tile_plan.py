@@ -37,7 +37,7 @@ def brute(rows, cus, cost3, big, slice_trees=0):
         rem = rows - r3
         c2, c3 = 100 * waves(rem, 128, cus), cost3 * waves(rem, big, cus)
         if r3 > 0 and rem_slices(rem, cus, slice_trees) > 1:
-            c2 = min(c2, 100 // rem_slices(rem, cus, slice_trees) + 35)
+            c2 = min(c2, 100 // rem_slices(rem, cus, slice_trees) + 20)
         cost = cost3 * waves(r3, big, cus) + min(c2, c3)
         if best is None or cost < best[0]:
             best = (cost, r3 if rem else 0, (2 if c2 <= c3 else 3) if rem else 3)
@@ -58,7 +58,7 @@ def test_plan_is_the_cheapest_cut(probe):
         assert rows3 % 384 == 0 and rows3 <= rows and chains in (2, 3), (rows, cus, rows3, chains)
         rem = rows - rows3
         s = rem_slices(rem, cus, trees) if rows3 > 0 else 1
-        c2 = min(100 * waves(rem, 128, cus), 100 // s + 35) if s > 1 else 100 * waves(rem, 128, cus)
+        c2 = min(100 * waves(rem, 128, cus), 100 // s + 20) if s > 1 else 100 * waves(rem, 128, cus)
         cost = cost3 * waves(rows3, big, cus) + (cost3 * waves(rem, big, cus) if chains == 3 else c2)
         assert cost == brute(rows, cus, cost3, big, trees)[0], (rows, cus, cost3, big, trees, rows3, chains)
 
@@ -67,8 +67,8 @@ def test_known_plans_and_forced_forms(probe):
     # K3 on 256 CUs: 20 waves of 192-row tiles + 16,960 rows in 128-row tiles; one of 8 GPUs' share: 2 waves + 26,696 rows;
     # KR3 on u8 codes: 10 waves of 384-row tiles + the same remainder; forced forms leave the cut to the caller
     # with tree slices for small remainders (1000 trees): 250 k rows = 5 waves of 192-row tiles + 34 tiles of 128 in 7 slices each
-    # (without: 4 waves + 418 tiles of 128); 500 k rows: 9 waves + 451 plain tiles still price one unit below 10 waves + 67 tiles in 3 slices
+    # (without: 4 waves + 418 tiles of 128), 500 k rows = 10 waves + 67 tiles in 3 slices
     inp = ("1000000 256 0 133 192 0\n125000 256 0 133 192 0\n1000000 256 0 218 384 0\n125000 256 0 218 384 0\n1000000 256 2 133 192 0\n"
            "1000000 256 3 133 192 0\n250000 256 0 133 192 0\n250000 256 0 133 192 1000\n500000 256 0 133 192 1000\n1000000 256 0 133 192 1000\n")
     out = subprocess.run([probe], input=inp, capture_output=True, text=True, check=True).stdout.split()
-    assert out == ["983040", "2", "98304", "2", "983040", "2", "98304", "2", "0", "2", "0", "3", "196608", "2", "245760", "2", "442368", "2", "983040", "2"]
+    assert out == ["983040", "2", "98304", "2", "983040", "2", "98304", "2", "0", "2", "0", "3", "196608", "2", "245760", "2", "491520", "2", "983040", "2"]
