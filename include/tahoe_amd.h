@@ -276,8 +276,9 @@ typedef struct {
     int ring_rows;           /* rows per TILERING tile: 64 or 128; 32 / 16 / 8 for the wide-row float32 form (num_cols > 512);
                               * 0 = strategy unavailable */
     int tilering_lds_bytes;  /* dynamic LDS of the TILERING kernel the launch takes (of the wide-row form where that runs) */
-    int qring_tile_rows;     /* rows per quantised tile in LDS: 128, or 64 / 32 / 16 for wide rows (several trees per
-                              * wave); 0 = features read from the quantised tile in L2, or QRING unavailable */
+    int qring_tile_rows;     /* rows per quantised tile in LDS: 384 (8-bit ranks, or <= 128 features), 192 (region form), 128, or
+                              * 64 / 32 / 16 for wide rows (several trees per wave); 0 = features read from the quantised tile in
+                              * L2, or QRING unavailable.  The large tile of the form: a batch may end in 128-row tiles. */
     int relayout;            /* 1: created with TAHOE_CREATE_PROB_RELAYOUT */
     size_t relayout_swaps;   /* internal nodes whose subtrees changed places */
     int stream_slots;        /* > 0: TILERING runs as the row-streaming kernel on 16-bit keys (picked at create by the shape
