@@ -719,7 +719,10 @@ static int resolve_strategy(const tahoe_forest *f, size_t rows)
     // very shallow trees (the whole tree sits in ROWTILE's LDS top, no pre-pass) and to the float32 tile kernels
     // when there is little walking per feature value (trees x depth < 6.5 x cols).  On ten shapes it was not fitted
     // on (--holdout) it picks the fastest strategy on 8 and stays within 1.16x on the other two.
-    const bool shallow = f->depth <= 4 && rowtile_fits(f);
+    // (round 4: only while there is little of it -- trees x depth <= 1024.  With 384-row tiles on narrow / few-threshold forests QRING
+    // overtook ROWTILE on large shallow forests: 2000 trees x depth 3 x 32 features 0.85 against 0.99 ms, 800 x 4 x 100 0.38 against 0.58,
+    // while 100 x 4 x 16 and 30 x 3 x 8 stay with ROWTILE, profiles/r04/selector_*.json)
+    const bool shallow = f->depth <= 4 && rowtile_fits(f) && (long long)f->p.num_trees * f->depth <= 1024;
     // (wide rows whose quantised form walks three trees per lane: that form is ~1.25 x faster, the float32 form pays off later)
     const long long per_col = qwide_chains(f) == 3 ? 10 : 13;
     const bool little_work = 2LL * f->p.num_trees * f->depth < per_col * f->p.num_cols &&
