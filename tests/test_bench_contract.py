@@ -127,3 +127,22 @@ def test_walk_ceiling_and_config_roofline_arithmetic():
     assert kind == "dense" and (T, D, C) == (500, 8, 18) and data.shape == (10_000, 18) and nodes.size == T * 511
     kind, (sn, tr, C5), _ = bench.baseline_workload(ta, "K5")
     assert kind == "sparse" and tr.size == 2000 and C5 == 256 and 9_000_000 < sn.size < 10_500_000
+
+
+def test_every_stamped_profile_of_the_round_belongs_to_these_sources():
+    """Counter profiles and selector runs of profiles/r04 carry src_hash = bench.kernel_source_hash() of the tree they were
+    measured on; all of them were re-taken on the final sources (a stale file would be a claim about other kernels)."""
+    import sys
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    want = bench.kernel_source_hash()
+    names = ["pmc_k1.json", "pmc_k2.json", "pmc_k3.json", "pmc_k4.json", "pmc_k5.json", "pmc_kr3.json", "selector_vs_enumeration.json",
+             "selector_holdout.json", "selector_realistic.json", "selector_wide.json"]
+    for name in names:
+        assert json.load(open(os.path.join(ROOT, "profiles", "r04", name)))["src_hash"] == want, name
+    line = recorded_line()
+    assert line["roofline"]["kernel_source_hash"] == want
+    for k in ("K1", "K2", "K5", "KR3"):
+        assert line["configs"][k]["roofline"]["counters"]["src_hash"] == want, k
