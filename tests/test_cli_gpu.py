@@ -26,6 +26,28 @@ def test_cli_protocol(built, case):
     assert "Using strategy 5" in out or "Strategy 5 is not suitable for this case." in out
 
 
+def test_cli_on_a_histogram_style_model(built, tmp_path):
+    """The CLI end to end on a forest in the style of histogram-trained models, written in the reference's text formats
+    (BaseTahoeTest.h:267-402): 28 features, <= 254 thresholds each, 30 k rows with missing values -- strategy 5 walks it on 8-bit
+    rank codes in 384-row tiles; every strategy must pass the CPU check of the harness."""
+    import tahoe_amd as ta
+
+    T, D, C, R = 150, 6, 28, 30_000
+    nodes = ta.synth_forest_hist(T, D, C, seed=77, feature_seed=5, max_bins=254, scale_decades=2.0)
+    data = ta.synth_data_hist(R, C, seed=78, feature_seed=5, scale_decades=2.0, missing_prob=0.01, missing=-999.0)
+    ta.write_model(str(tmp_path / "m.txt"), nodes, T, D)
+    ta.write_data(str(tmp_path / "d.txt"), data, -999.0)
+    f = ta.Forest(nodes, T, D, C, missing=-999.0)
+    assert f.kernel_form(R) == "qring_region8"
+    f.close()
+    exe = os.path.join(ROOT, "tahoe_amd", "host", "Tahoe")
+    r = subprocess.run([exe, str(tmp_path / "m.txt"), str(tmp_path / "d.txt")], capture_output=True, text=True, timeout=300)
+    out = r.stdout
+    assert r.returncode == 0, out + r.stderr
+    assert "Results are incorrect" not in out and "FAIL:" not in out and "Using strategy 5" in out
+    assert out.count("Results are correct") == 1 + len(re.findall(r"^Using strategy \d", out, flags=re.M))
+
+
 def test_cli_result_json_and_leaf_dump(built, tmp_path):
     """TAHOE_RESULT_JSON / TAHOE_LEAF_DUMP: the machine-readable summary, and per-(row, tree) leaf indices that equal
     the oracle's on the golden case."""
