@@ -293,7 +293,9 @@ typedef struct {
 tahoe_status tahoe_forest_get_info(const tahoe_forest *f, tahoe_forest_info *info);
 
 /* Which kernel a predict of `rows` rows launches (one strategy number can stand for several kernels: TILERING is
- * tilering_kernel, widef_kernel or wkey_kernel; QRING has five tile forms).  -1 for a NULL handle. */
+ * tilering_kernel, widef_kernel or wkey_kernel; QRING has several tile forms).  -1 for a NULL handle.
+ * REGION8 / REGION6 name the code layout: whole waves of the batch go through 384-row tiles, a remainder (or a batch too small
+ * for one wave of them) through 128-row tiles of the same codes in a second launch, as REGION_MIXED does for 192 + 128. */
 enum {
     TAHOE_FORM_NONE = 0,                  /* strategy unavailable for this shape */
     TAHOE_FORM_DIRECT = 1,                /* direct_kernel */
