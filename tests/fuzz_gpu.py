@@ -48,9 +48,25 @@ while time.time() < t_end:
         want, want_leaf = oracle.predict(nodes, T, D, data, MISSING, want_leaf=True, threads=8)
         stream_form = C > 512 and rng.random() < 0.5  # TILERING as the row-streaming kernel (read at create)
         os.environ["TAHOE_WSTREAM"] = "1" if stream_form else "0"
+        # the create-time knobs that steer QRING between its forms: a quarter of the cases take a draw of them, so that the forms AUTO
+        # would not pick for this shape (u16 codes on few thresholds, the 32-KiB stride on narrow forests, forced tile plans, no slices,
+        # the column layout, the pair quantise kernels) meet the same oracle
+        knobs = {}
+        if rng.random() < 0.25:
+            for name, values in (("TAHOE_QRING_CODE8", ["0"]), ("TAHOE_QRING_NARROW128", ["0"]), ("TAHOE_QRING_CHAINS", ["2", "3"]),
+                                 ("TAHOE_QRING_SLICES", ["1", "3"]), ("TAHOE_QRING_REGIONS", ["0"]), ("TAHOE_QUANT_MULTI", ["0"]),
+                                 ("TAHOE_QUANT_BUCKETS", ["0"])):
+                if rng.random() < 0.3:
+                    knobs[name] = str(rng.choice(values))
+        os.environ.update(knobs)
         f = ta.Forest(nodes, T, D, C, missing=MISSING)
+        for name in knobs:
+            del os.environ[name]
         strategies = [ta.STRATEGY_AUTO, ta.STRATEGY_DIRECT, ta.STRATEGY_ROWTILE, ta.STRATEGY_TILEBLOCK, ta.STRATEGY_TILERING, ta.STRATEGY_QRING]
-        desc = f"dense T={T} D={D} C={C} R={R} missing={mp}" + (" wstream" if stream_form else "") + (f" hist bins={bins} decades={dec}" if hist else "")
+        if knobs:  # the knobs touch QRING only: the float32 strategies of this forest were covered without them
+            strategies = [ta.STRATEGY_AUTO, ta.STRATEGY_QRING]
+        desc = (f"dense T={T} D={D} C={C} R={R} missing={mp}" + (" wstream" if stream_form else "") + (f" hist bins={bins} decades={dec}" if hist else "")
+                + "".join(f" {k[6:]}={v}" for k, v in knobs.items()))
     for s in strategies:
         try:
             f.set_strategy(s)
